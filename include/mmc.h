@@ -1,0 +1,117 @@
+/*
+ * mmc.h -- C ABI of libmermaid_mi355.so: the MI355X (gfx950) implementation of the
+ * PySpacer EfficientNet patch feature-extraction path of data-mermaid/mermaid-classifier.
+ *
+ * The reference has no FFI; its "plugin API" for this path is a Python class contract
+ * plus three file artifacts.  Every entry point below names the reference
+ * interface it replaces.  Plain C: no exceptions cross the boundary, every call returns an
+ * int status (0 = MMC_OK) and mmc_last_error() returns a thread-local message.
+ * All buffers are caller-owned; handles are opaque; streams are explicit (hipStream_t
+ * passed as void*, NULL = the default stream).  No torch types appear here.
+ */
+#ifndef MMC_H
+#define MMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMC_OK 0
+#define MMC_ERR_ARG 1      /* bad argument / shape (ValueError on the Python side) */
+#define MMC_ERR_WEIGHTS 2  /* packed weights blob malformed (KeyError/ValueError) */
+#define MMC_ERR_HIP 3      /* HIP runtime failure (RuntimeError) */
+#define MMC_ERR_NOMEM 4
+
+#define MMC_ARCH_B0 0
+
+/* memory-kind flags for mmc_backbone_extract / mmc_head_predict / mmc_crop_patches */
+#define MMC_IN_DEVICE 0u
+#define MMC_IN_HOST 1u   /* `patches`/`feats`/`image` is host memory: staged with hipMemcpyAsync */
+#define MMC_OUT_DEVICE 0u
+#define MMC_OUT_HOST 2u  /* outputs are host memory; the call synchronises the stream before returning */
+
+#define MMC_FEATURE_DIM_B0 1280
+#define MMC_PATCH 224
+
+typedef struct mmc_backbone mmc_backbone;
+typedef struct mmc_head mmc_head;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* mmc_last_error(void);
+int mmc_version(void);          /* ABI version, currently 1 */
+int mmc_device_count(void);     /* number of visible HIP devices (0 when none) */
+
+/* ---- backbone ------------------------------------------------------------------------
+ * Replaces: EfficientNetExtractor.load_weights(stream) + net.to(device).eval()
+ *   (reference scripts/build_feature_bucket.py:402-413) and
+ *   net.extract_features(batch) (scripts/build_feature_bucket.py:430-437), including the
+ *   per-patch transformation() (ToTensor + Normalize, :420-423), which is folded into the
+ *   stem kernel: the library takes raw u8 HWC patches.
+ *
+ * `packed` is the blob produced by mermaid_classifier_amd.weights.pack_backbone():
+ *   header  { char magic[4]="MMCW"; u32 version=1; u32 arch; u32 n_tensors; }
+ *   table   n_tensors x { u64 offset; u64 nbytes; }          (offsets from blob start, 256-B aligned)
+ *   tensors in the fixed order documented in mermaid_classifier_amd/weights.py
+ *   (BN folded: fp16 GEMM weights in MFMA-row-permuted [Np][Kp] layout, fp32 biases,
+ *    fp32 depthwise taps [k*k][C], fp32 squeeze-excite matrices).
+ * The blob is copied to device memory; the caller may free it after the call.
+ * `max_batch` bounds the activation workspace (patches processed per internal pass).
+ */
+int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device, int max_batch,
+                        mmc_backbone** out);
+void mmc_backbone_destroy(mmc_backbone* bb);
+int mmc_feature_dim(const mmc_backbone* bb);            /* 1280 for B0 */
+int mmc_backbone_max_batch(const mmc_backbone* bb);
+size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb);
+
+/* patches: n x 224 x 224 x 3 u8 (HWC, RGB).  out_features: n x feature_dim fp32, row i = patch i.
+ * flags: MMC_IN_HOST | MMC_OUT_HOST select host pointers; default both device pointers.
+ * Asynchronous on `hip_stream` unless MMC_OUT_HOST is set. */
+int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
+                         unsigned flags, void* hip_stream);
+
+/* Debug/parity hook: copy one intermediate activation of the LAST internal pass to host.
+ * name: "stem", "b<i>.expand", "b<i>.dw", "b<i>.gate", "b<i>.out".  fp16 NHWC tensors are returned
+ * as fp32 NHWC; gates as fp32 (n,C).  `capacity` = number of floats available in `out`;
+ * *n_written receives the element count.  Requires MMC_KEEP_ACTIVATIONS=1 at create time
+ * (separate buffers per layer); used only by the parity tests. */
+int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, float* out, size_t capacity,
+                                 size_t* n_written);
+
+/* Kernel timing hook for bench.py: runs `iters` passes over `n` resident patches and returns the
+ * HIP-event elapsed milliseconds of each named kernel class, measured on `hip_stream`.
+ * names/ms arrays have `cap` slots; *n_out receives the number filled. */
+int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, float* out_features_dev,
+                         void* hip_stream, char (*names)[48], float* ms, int* launches, int cap, int* n_out);
+
+/* ---- GPU crop front-end ---------------------------------------------------------------
+ * Replaces: pyspacer crop_patches(image, rowcols, 224) as called by FeatureExtractor.__call__
+ *   (reached from scripts/build_feature_bucket.py:775 and
+ *    mermaid_classifier/pyspacer/annotation.py:241): reflect-pad by 224, slice 224x224 around
+ *   each (row,col).  Implemented as index arithmetic on the resident image (no padded copy).
+ * image: H x W x 3 u8; rowcols: n x 2 int32 (row, col); patches_out: n x 224 x 224 x 3 u8 (device). */
+int mmc_crop_patches(const void* image, int height, int width, const int32_t* rowcols, int64_t n,
+                     void* patches_out_dev, unsigned flags, int device, void* hip_stream);
+
+/* ---- calibrated MLP head -------------------------------------------------------------
+ * Replaces: CalibratedHead.forward (mermaid_classifier/pyspacer/inference/head.py:66-89) as run by
+ *   Predictor.predict_proba (mermaid_classifier/pyspacer/inference/loader.py:30-35).
+ * W[l]: (dims[l+1], dims[l]) row-major fp32 (torch nn.Linear layout); b[l]: (dims[l+1]);
+ * dims has n_layers+1 entries, dims[n_layers] == K; a, bcal: (K) Platt parameters.  All host pointers.
+ */
+int mmc_head_create(const float* const* W, const float* const* b, const int* dims, int n_layers,
+                    const float* a, const float* bcal, int K, int device, mmc_head** out);
+void mmc_head_destroy(mmc_head* h);
+int mmc_head_input_dim(const mmc_head* h);
+int mmc_head_num_classes(const mmc_head* h);
+/* feats: n x input_dim fp32; proba: n x K fp32; argmax: n int32 (may be NULL). */
+int mmc_head_predict(mmc_head* h, const float* feats, int64_t n, float* proba, int32_t* argmax,
+                     unsigned flags, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMC_H */

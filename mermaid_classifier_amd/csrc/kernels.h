@@ -1,0 +1,46 @@
+// kernels.h -- launcher interface between mmc_api.cpp (network schedule, C ABI) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { EPI_SILU = 0, EPI_LINEAR = 1, EPI_GAP = 2 };
+
+struct GemmArgs {
+    const _Float16* X;   // [M][K] activations (NHWC rows)
+    int M, K;
+    const _Float16* Wp;  // [n_chunks*16*nt][Kp] row-permuted, zero padded
+    int Kp;
+    const float* bias;   // [n_chunks*16*nt] natural channel order, zero padded
+    _Float16* Y;         // [M][N]
+    int N;
+    int mt, nt, n_chunks;
+    int epi;
+    const float* gate;   // [patch][K] or null
+    int HW;              // rows per patch
+    const _Float16* res; // [M][N] or null
+    float* gap_out;      // EPI_GAP: [patches][N]
+    float inv_hw;
+};
+
+struct DwArgs {
+    const _Float16* in;
+    const float* wt;     // [ks*ks][C]
+    const float* bias;   // [C]
+    _Float16* out;
+    float* pool_part;    // [B][parts][C]
+    int B, H, W, C, Ho, Wo, pad_t, pad_l;
+    int ks, stride, tw;
+    int CG, S, iters, parts;
+};
+
+int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
+                hipStream_t st);
+int launch_pw_gemm(const GemmArgs& a, hipStream_t st);
+int launch_dwconv(const DwArgs& a, hipStream_t st);
+int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs, float inv_hw, const float* Wr,
+                   const float* br, const float* We, const float* be, float* gate, hipStream_t st);
+int launch_mlp_layer(const float* X, int M, int K, const float* W, const float* bias, float* Y, int N, bool relu,
+                     hipStream_t st);
+int launch_calibrate(const float* logits, int M, int K, const float* a, const float* b, float* proba, int32_t* argmax,
+                     hipStream_t st);
+int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int n, uint8_t* out, hipStream_t st);

@@ -1,0 +1,676 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels for the EfficientNet-B0 patch
+// feature-extraction path.  gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x32_f16,
+// v_mfma_f32_16x16x4_f32, LDS.  No CUDA compatibility paths.
+//
+// Data layout in HBM: activations are NHWC fp16 ([patch][y][x][channel]); channel counts are
+// multiples of 8 so every lane moves 16-byte vectors.  Accumulation is always fp32.
+//
+// What each kernel replaces in the reference's call graph (pyspacer EfficientNet.extract_features,
+// invoked at scripts/build_feature_bucket.py:434):
+//   stem_conv_kernel   transformation() + _conv_stem + _bn0 + swish
+//   pw_gemm_kernel     _expand_conv+_bn0+swish | SE-scale + _project_conv+_bn2(+skip) | _conv_head+_bn1+swish+avgpool
+//   dwconv_kernel      _depthwise_conv + _bn1 + swish, plus the squeeze-excite partial sums
+//   se_gate_kernel     adaptive_avg_pool2d + _se_reduce + swish + _se_expand + sigmoid
+//   mlp_gemm_f32_kernel / calibrate_kernel   CalibratedHead.forward (inference/head.py:66-89)
+//   crop_kernel        pyspacer crop_patches (reflect pad + slice)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+static __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Stem: u8 HWC patch -> conv3x3 stride 2 (TF-same: pad right/bottom by 1) -> +bias -> SiLU -> fp16
+// One workgroup = 16x16 output pixels of one patch; wave w owns output rows 4w..4w+3, one MFMA
+// fragment (16 pixels x 32 channels) per row.  The 33x33x3 input tile is staged in LDS as exact
+// fp16 integers (u8 - 128); normalisation (x/255-mean)/std is folded into weights and bias on the
+// host, and padded pixels hold 255*mean-128 so they contribute exactly the folded zero.
+// K packing (32 slots = 4 lane-quarters x 8): quarter q<3 = kernel row q, bytes 0..7 of the 9-byte
+// (kx,c) run; quarter 3 = byte 8 of rows 0,1,2 then zeros.  Weights are packed to match on the host.
+// ---------------------------------------------------------------------------------------------
+#define STEM_TILE 16
+#define STEM_IN (2 * STEM_TILE + 1)   // 33
+#define STEM_ROWH 104                 // halves per LDS row (99 used), keeps rows 16-B aligned
+
+__global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restrict__ patches,  // [B][224][224][3]
+                                                        const _Float16* __restrict__ w,        // [32][32] (n, kslot)
+                                                        const float* __restrict__ bias,        // [32]
+                                                        const float* __restrict__ padval,      // [3]  255*mean-128
+                                                        _Float16* __restrict__ out)            // [B][112][112][32]
+{
+    __shared__ __attribute__((aligned(16))) _Float16 tile[STEM_IN * STEM_ROWH];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const uint8_t* img = patches + (size_t)b * (224 * 224 * 3);
+    const int iy0 = ty * 32, ix0 = tx * 32;
+    const float pv0 = padval[0], pv1 = padval[1], pv2 = padval[2];
+    // stage: 33 rows x 25 dwords
+    for (int i = tid; i < STEM_IN * 25; i += 256) {
+        const int r = i / 25, d = i - r * 25;
+        const int iy = iy0 + r;
+        const int boff = ix0 * 3 + d * 4;  // byte offset inside the image row
+        uint32_t word = 0;
+        const bool row_ok = iy < 224;
+        if (row_ok && boff < 672) word = *reinterpret_cast<const uint32_t*>(img + (size_t)iy * 672 + boff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int bb = d * 4 + e;  // byte inside the tile row
+            if (bb < 99) {
+                const int col = ix0 + bb / 3;
+                const int c = bb % 3;
+                float v;
+                if (row_ok && col < 224) v = (float)((word >> (8 * e)) & 0xffu) - 128.0f;
+                else v = (c == 0) ? pv0 : (c == 1 ? pv1 : pv2);
+                tile[r * STEM_ROWH + bb] = (_Float16)v;
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    // weight fragments (A operand): rows = output channels
+    h8 wf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
+    float bs[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[t * 4 + j] = bias[q * 8 + t * 4 + j];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int oyl = wave * 4 + f;  // local output row
+        h8 a;
+        if (q < 3) {
+            const _Float16* src = tile + (2 * oyl + q) * STEM_ROWH + 6 * m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = src[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (_Float16)0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[j] = tile[(2 * oyl + j) * STEM_ROWH + 6 * m + 8];
+        }
+        f4 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], a, acc[t], 0, 0, 0);
+        }
+        const int oy = ty * 16 + oyl, ox = tx * 16 + m;
+        h8 o;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_f(acc[t][j] + bs[t * 4 + j]);
+        *reinterpret_cast<h8*>(out + (((size_t)b * 112 + oy) * 112 + ox) * 32 + q * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1) convolution as an MFMA GEMM:  Y[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] ).
+// Operands are swapped (weights = MFMA A operand, activations = B operand) so that the fp32 result
+// fragment holds, per lane, 4*NT CONSECUTIVE output channels of one pixel -> 8-byte stores that
+// coalesce to full lines.  The host packs W row-permuted per chunk of 16*NT channels:
+//   packed row (chunk*16NT + t*16 + 4q + j)  <->  channel (chunk*16NT + q*4NT + 4t + j).
+// Each wave owns MT fragments of 16 rows (pixels); a workgroup is 4 waves = 64*MT rows;
+// blockIdx.y selects the channel chunk.  Activation fragments are loaded straight from HBM/L2 into
+// registers (16 B per lane); weight fragments come through L1/L2 (weights are small and shared).
+// EPI_SILU   : y = silu(acc+bias)                              (expand conv)
+// EPI_LINEAR : y = acc+bias (+ residual)                       (project conv), optional SE gate on X
+// EPI_GAP    : out[patch][n] = mean over the patch's HW rows of silu(acc+bias)   (head conv + avgpool)
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int EPI, bool GATE, bool RES>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict__ X, int M, int K,
+                                                      const _Float16* __restrict__ Wp, int Kp,
+                                                      const float* __restrict__ bias,  // natural channel order, zero padded to [Np]
+                                                      _Float16* __restrict__ Y, int N,
+                                                      const float* __restrict__ gate,  // [patch][K] fp32
+                                                      int HW,
+                                                      const _Float16* __restrict__ res,
+                                                      float* __restrict__ gap_out, float inv_hw)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.y;
+    const _Float16* wbase = Wp + ((size_t)chunk * 16 * NT + m) * Kp + q * 8;
+    int row[MT];
+    bool rok[MT];
+    int gpatch[MT];
+    if (EPI == EPI_GAP) {
+        // one workgroup = one patch; rows beyond HW are masked
+        const int ml = wave * 16 + m;
+        row[0] = blockIdx.x * HW + ml;
+        rok[0] = ml < HW;
+        gpatch[0] = blockIdx.x;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            row[i] = (blockIdx.x * 4 + wave) * (16 * MT) + i * 16 + m;
+            rok[i] = row[i] < M;
+            gpatch[i] = GATE ? (rok[i] ? row[i] / HW : 0) : 0;
+        }
+    }
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        const int k = k0 + q * 8;
+        const bool kok = k < K;
+        h8 xf[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kok && rok[i]) v = *reinterpret_cast<const h8*>(X + (size_t)row[i] * K + k);
+            if (GATE) {
+                if (kok && rok[i]) {
+                    const f4 g0 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k);
+                    const f4 g1 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = (_Float16)((float)v[j] * g0[j]);
+                        v[4 + j] = (_Float16)((float)v[4 + j] * g1[j]);
+                    }
+                }
+            }
+            xf[i] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h8 wf = *reinterpret_cast<const h8*>(wbase + (size_t)t * 16 * Kp + k0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[i], acc[i][t], 0, 0, 0);
+        }
+    }
+    // epilogue: lane (m,q) holds channels cbase + q*4NT + 4t + j of pixel row[i]
+    const int cbase = chunk * 16 * NT + q * 4 * NT;
+    float bs[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f4 bv = *reinterpret_cast<const f4*>(bias + cbase + 4 * t);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[t][j] = bv[j];
+    }
+    if (EPI == EPI_GAP) {
+        __shared__ float red[4][16 * NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = rok[0] ? silu_f(acc[0][t][j] + bs[t][j]) : 0.0f;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (m == 0) red[wave][q * 4 * NT + 4 * t + j] = v;
+            }
+        __syncthreads();
+        if (tid < 16 * NT) {
+            const float s = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * inv_hw;
+            const int c = chunk * 16 * NT + tid;
+            if (c < N) gap_out[(size_t)blockIdx.x * N + c] = s;
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (!rok[i]) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = cbase + 4 * t;
+            if (c < N) {  // N is a multiple of 4
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][t][j] + bs[t][j];
+                if (EPI == EPI_SILU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                }
+                if (RES) {
+                    const h4 r = *reinterpret_cast<const h4*>(res + (size_t)row[i] * N + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                }
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+                *reinterpret_cast<h4*>(Y + (size_t)row[i] * N + c) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise KSxKS convolution, stride ST, TF-same padding, + bias (BN folded) + SiLU, fp16 out,
+// plus per-(patch, channel) partial sums of the fp32 SiLU outputs for squeeze-excite.
+// Thread = 8 channels x TW consecutive output pixels of one row; channel-group index is the fastest
+// thread index so neighbouring lanes read neighbouring 16-byte vectors (coalesced NHWC).
+// blockDim.x = CG*S (CG = C/8 channel groups, S strips per pass).  Partial sums are reduced through
+// LDS in a fixed order and written to pool_part[patch][blockIdx.x][C] (deterministic, no atomics).
+// ---------------------------------------------------------------------------------------------
+template <int KS, int ST, int TW>
+__global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict__ in,  // [B][H][W][C]
+                                                     const float* __restrict__ wt,     // [KS*KS][C]
+                                                     const float* __restrict__ bias,   // [C]
+                                                     _Float16* __restrict__ out,       // [B][Ho][Wo][C]
+                                                     float* __restrict__ pool_part,    // [B][gridDim.x][C]
+                                                     int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l,
+                                                     int CG, int S, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [S][C]
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, s = tid / CG;
+    const int b = blockIdx.y;
+    const int strips_per_row = Wo / TW;
+    const int nstrips = Ho * strips_per_row;
+    const int c0 = cg * 8;
+    const _Float16* inb = in + (size_t)b * H * W * C + c0;
+    _Float16* outb = out + (size_t)b * Ho * Wo * C + c0;
+    float bs[8];
+    {
+        const f4 b0 = *reinterpret_cast<const f4*>(bias + c0);
+        const f4 b1 = *reinterpret_cast<const f4*>(bias + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
+    }
+    float pooled[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pooled[j] = 0.f;
+    constexpr int NX = (TW - 1) * ST + KS;  // input columns a strip touches
+    for (int it = 0; it < iters; ++it) {
+        const int strip = (blockIdx.x * iters + it) * S + s;
+        if (strip < nstrips) {
+            const int oy = strip / strips_per_row;
+            const int ox0 = (strip - oy * strips_per_row) * TW;
+            float acc[TW][8];
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * ST - pad_t + ky;
+                if (iy < 0 || iy >= H) continue;
+                const _Float16* rowp = inb + (size_t)iy * W * C;
+                float wk[KS][8];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f4 w0 = *reinterpret_cast<const f4*>(wt + (size_t)(ky * KS + kx) * C + c0);
+                    const f4 w1 = *reinterpret_cast<const f4*>(wt + (size_t)(ky * KS + kx) * C + c0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
+                }
+#pragma unroll
+                for (int xr = 0; xr < NX; ++xr) {
+                    const int ix = ox0 * ST - pad_l + xr;
+                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ix >= 0 && ix < W) v = *reinterpret_cast<const h8*>(rowp + (size_t)ix * C);
+                    float vf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vf[j] = (float)v[j];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        const int kx = xr - t * ST;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[t][j] = __builtin_fmaf(vf[j], wk[kx][j], acc[t][j]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                h8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = silu_f(acc[t][j] + bs[j]);
+                    pooled[j] += y;
+                    o[j] = (_Float16)y;
+                }
+                *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox0 + t) * C) = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[s * C + c0 + j] = pooled[j];
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        float sum = 0.f;
+        for (int ss = 0; ss < S; ++ss) sum += red[ss * C + c];
+        pool_part[((size_t)b * gridDim.x + blockIdx.x) * C + c] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Squeeze-excite gate: one workgroup per patch.
+//   pooled[c] = inv_hw * sum_p pool_part[b][p][c]
+//   r[j]      = silu(b_r[j] + sum_c W_r[j][c] pooled[c])        j < Cs   (wave-reduced dot products)
+//   gate[c]   = sigmoid(b_e[c] + sum_j W_e[c][j] r[j])
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
+                                                      float inv_hw, const float* __restrict__ Wr,
+                                                      const float* __restrict__ br, const float* __restrict__ We,
+                                                      const float* __restrict__ be, float* __restrict__ gate)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C] + r[Cs]
+    float* pooled = sm;
+    float* r = sm + C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* pp = pool_part + (size_t)b * nparts * C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < nparts; ++p) s += pp[(size_t)p * C + c];
+        pooled[c] = s * inv_hw;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += Wr[(size_t)j * C + c] * pooled[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) r[j] = silu_f(s + br[j]);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = be[c];
+        for (int j = 0; j < Cs; ++j) s += We[(size_t)c * Cs + j] * r[j];
+        gate[(size_t)b * C + c] = sigmoid_f(s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Calibrated MLP head, fp32 end to end (the reference gate is max|dp| <= 1e-6, inference/export.py:31).
+// Y[m][n] = act( sum_k X[m][k] W[n][k] + b[n] ) on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
+// Lane (i=l&15, q=l>>4) loads 4 consecutive k of its row (16 B) and feeds element s at step s, so
+// the 16 k of a group are covered by 4 MFMAs with both operands using the same k permutation.
+// Workgroup = 4 waves; wave w owns rows [16*(4*bx+w), +16) and NT fragments of 16 output columns.
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool RELU>
+__global__ __launch_bounds__(256) void mlp_gemm_f32_kernel(const float* __restrict__ X, int M, int K,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ Y, int N)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + i;
+    const bool rok = row < M;
+    const int n0 = blockIdx.y * 16 * NT;
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    const int K16 = K & ~15;
+    for (int k0 = 0; k0 < K16; k0 += 16) {
+        f4 xv = {0.f, 0.f, 0.f, 0.f};
+        if (rok) xv = *reinterpret_cast<const f4*>(X + (size_t)row * K + k0 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 16 + i;
+            f4 wv = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) wv = *reinterpret_cast<const f4*>(W + (size_t)n * K + k0 + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t], 0, 0, 0);
+        }
+    }
+    if (K16 < K) {  // K tail (K % 16 != 0): scalar-guarded loads, K is a multiple of 4 for every head layer
+        f4 xv = {0.f, 0.f, 0.f, 0.f};
+        const int k = K16 + 4 * q;
+        if (rok && k < K) xv = *reinterpret_cast<const f4*>(X + (size_t)row * K + k);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 16 + i;
+            f4 wv = {0.f, 0.f, 0.f, 0.f};
+            if (n < N && k < K) wv = *reinterpret_cast<const f4*>(W + (size_t)n * K + k);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t], 0, 0, 0);
+        }
+    }
+    // swapped operands: lane (i,q) holds outputs n = n0 + 16t + 4q + j of row `row`
+    if (!rok) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + t * 16 + 4 * q + j;
+            if (n < N) {
+                float v = acc[t][j] + bias[n];
+                if (RELU) v = fmaxf(v, 0.f);
+                Y[(size_t)row * N + n] = v;
+            }
+        }
+}
+
+// One wave per row: softmax -> Platt sigmoid -> row normalise (uniform row when the sum is 0)
+// -> sklearn overshoot clip -> argmax (first maximum, like numpy/torch argmax).   head.py:75-89
+__global__ __launch_bounds__(256) void calibrate_kernel(const float* __restrict__ logits, int M, int K,
+                                                        const float* __restrict__ a, const float* __restrict__ bcal,
+                                                        float* __restrict__ proba, int32_t* __restrict__ argmax_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = logits + (size_t)row * K;
+    float mx = -INFINITY;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, x[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f;
+    for (int k = lane; k < K; k += 64) se += expf(x[k] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    float cs = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float p = expf(x[k] - mx) / se;
+        const float c = 1.0f / (1.0f + expf(a[k] * p + bcal[k]));  // sigmoid(-(a p + b))
+        proba[(size_t)row * K + k] = c;
+        cs += c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int k = lane; k < K; k += 64) {
+        float v = (cs != 0.f) ? proba[(size_t)row * K + k] / cs : 1.0f / (float)K;
+        if (v > 1.0f && v <= 1.00001f) v = 1.0f;
+        proba[(size_t)row * K + k] = v;
+        if (v > best) { best = v; besti = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(besti, o);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (argmax_out && lane == 0) argmax_out[row] = besti;
+}
+
+// ---------------------------------------------------------------------------------------------
+// crop_patches: reflect-pad + slice as pure index arithmetic on the resident image.
+// numpy 'reflect': index i<0 -> -i ; i>=n -> 2(n-1)-i.  One thread = 4 output pixels (12 bytes).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ image, int H, int W,
+                                                   const int32_t* __restrict__ rowcols, uint8_t* __restrict__ out)
+{
+    const int p = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;  // over 224*56 groups of 4 pixels
+    if (idx >= 224 * 56) return;
+    const int y = idx / 56, xg = idx - y * 56;
+    const int row = rowcols[2 * p], col = rowcols[2 * p + 1];
+    int sy = row - 112 + y;
+    sy = sy < 0 ? -sy : sy;
+    sy = sy >= H ? 2 * (H - 1) - sy : sy;
+    uint32_t w[3] = {0, 0, 0};
+    uint8_t* wb = reinterpret_cast<uint8_t*>(w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int sx = col - 112 + xg * 4 + e;
+        sx = sx < 0 ? -sx : sx;
+        sx = sx >= W ? 2 * (W - 1) - sx : sx;
+        const uint8_t* src = image + ((size_t)sy * W + sx) * 3;
+        wb[3 * e + 0] = src[0];
+        wb[3 * e + 1] = src[1];
+        wb[3 * e + 2] = src[2];
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((size_t)p * 224 * 224 + (size_t)y * 224 + xg * 4) * 3);
+    dst[0] = w[0];
+    dst[1] = w[1];
+    dst[2] = w[2];
+}
+
+// =============================================================================================
+// Host-side launchers (plain C++ signatures declared in kernels.h)
+// =============================================================================================
+#define LAUNCH_CHECK()                          \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
+                hipStream_t st)
+{
+    dim3 grid(7, 7, B);
+    hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), 0, st, patches, w, bias, padval, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MT, int NT>
+static int launch_gemm_nt(const GemmArgs& a, hipStream_t st)
+{
+    const int rows_per_wg = 64 * MT;
+    dim3 grid((a.M + rows_per_wg - 1) / rows_per_wg, a.n_chunks, 1);
+    dim3 block(256);
+#define GEMM_GO(EPI, GATE, RES)                                                                                    \
+    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, EPI, GATE, RES>), grid, block, 0, st, a.X, a.M, a.K, a.Wp, a.Kp,   \
+                       a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw)
+    if (a.epi == EPI_SILU) GEMM_GO(EPI_SILU, false, false);
+    else if (a.epi == EPI_LINEAR) {
+        if (a.gate && a.res) GEMM_GO(EPI_LINEAR, true, true);
+        else if (a.gate) GEMM_GO(EPI_LINEAR, true, false);
+        else if (a.res) GEMM_GO(EPI_LINEAR, false, true);
+        else GEMM_GO(EPI_LINEAR, false, false);
+    } else return -1;
+#undef GEMM_GO
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NT>
+static int launch_gap_nt(const GemmArgs& a, hipStream_t st)
+{
+    dim3 grid(a.M / a.HW, a.n_chunks, 1);
+    hipLaunchKernelGGL((pw_gemm_kernel<1, NT, EPI_GAP, false, false>), grid, dim3(256), 0, st, a.X, a.M, a.K, a.Wp,
+                       a.Kp, a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
+{
+    if (a.epi == EPI_GAP) {
+        if (a.HW > 64) return -2;
+        switch (a.nt) {
+            case 4: return launch_gap_nt<4>(a, st);
+            case 5: return launch_gap_nt<5>(a, st);
+            case 8: return launch_gap_nt<8>(a, st);
+            default: return -3;
+        }
+    }
+#define CASE_NT(n)                                              \
+    case n:                                                     \
+        return a.mt == 2 ? launch_gemm_nt<2, n>(a, st) : launch_gemm_nt<1, n>(a, st);
+    switch (a.nt) {
+        CASE_NT(1)
+        CASE_NT(2)
+        CASE_NT(3)
+        CASE_NT(4)
+        CASE_NT(5)
+        CASE_NT(6)
+        CASE_NT(7)
+        CASE_NT(8)
+        default: return -3;
+    }
+#undef CASE_NT
+}
+
+template <int KS, int ST, int TW>
+static int launch_dw_t(const DwArgs& a, hipStream_t st)
+{
+    dim3 grid(a.parts, a.B, 1);
+    dim3 block(a.CG * a.S);
+    const size_t shm = (size_t)a.S * a.C * sizeof(float);
+    hipLaunchKernelGGL((dwconv_kernel<KS, ST, TW>), grid, block, shm, st, a.in, a.wt, a.bias, a.out, a.pool_part, a.H,
+                       a.W, a.C, a.Ho, a.Wo, a.pad_t, a.pad_l, a.CG, a.S, a.iters);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_dwconv(const DwArgs& a, hipStream_t st)
+{
+#define DW_CASE(KS, ST, TW) \
+    if (a.ks == KS && a.stride == ST && a.tw == TW) return launch_dw_t<KS, ST, TW>(a, st);
+    DW_CASE(3, 1, 4)
+    DW_CASE(3, 1, 2)
+    DW_CASE(3, 1, 7)
+    DW_CASE(3, 2, 4)
+    DW_CASE(3, 2, 2)
+    DW_CASE(3, 2, 7)
+    DW_CASE(5, 1, 4)
+    DW_CASE(5, 1, 2)
+    DW_CASE(5, 1, 7)
+    DW_CASE(5, 2, 4)
+    DW_CASE(5, 2, 2)
+    DW_CASE(5, 2, 7)
+#undef DW_CASE
+    return -4;
+}
+
+int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs, float inv_hw, const float* Wr,
+                   const float* br, const float* We, const float* be, float* gate, hipStream_t st)
+{
+    const size_t shm = (size_t)(C + Cs) * sizeof(float);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), shm, st, pool_part, nparts, C, Cs, inv_hw, Wr, br, We, be,
+                       gate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mlp_layer(const float* X, int M, int K, const float* W, const float* bias, float* Y, int N, bool relu,
+                     hipStream_t st)
+{
+    constexpr int NT = 4;
+    dim3 grid((M + 63) / 64, (N + 16 * NT - 1) / (16 * NT), 1);
+    if (relu)
+        hipLaunchKernelGGL((mlp_gemm_f32_kernel<NT, true>), grid, dim3(256), 0, st, X, M, K, W, bias, Y, N);
+    else
+        hipLaunchKernelGGL((mlp_gemm_f32_kernel<NT, false>), grid, dim3(256), 0, st, X, M, K, W, bias, Y, N);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_calibrate(const float* logits, int M, int K, const float* a, const float* b, float* proba, int32_t* argmax,
+                     hipStream_t st)
+{
+    hipLaunchKernelGGL(calibrate_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, M, K, a, b, proba, argmax);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int n, uint8_t* out, hipStream_t st)
+{
+    dim3 grid((224 * 56 + 255) / 256, n, 1);
+    hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, st, image, H, W, rowcols, out);
+    LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,692 @@
+// mmc_api.cpp -- C ABI (include/mmc.h) and the EfficientNet-B0 launch schedule.
+// Host C++ only; kernels live in kernels.hip.  No torch, no CUDA shims.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mmc.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(MMC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+#define KTRY(expr)                                                                                 \
+    do {                                                                                           \
+        int r_ = (expr);                                                                           \
+        if (r_ != 0) return fail(MMC_ERR_HIP, "%s failed (%d: %s)", #expr, r_,                     \
+                                 r_ > 0 ? hipGetErrorString((hipError_t)r_) : "unsupported shape"); \
+    } while (0)
+
+extern "C" const char* mmc_last_error(void) { return g_err; }
+extern "C" int mmc_version(void) { return 1; }
+extern "C" int mmc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// EfficientNet-B0 stage table (the published architecture; mirrors oracle/efficientnet_b0_ref.py)
+// ------------------------------------------------------------------------------------------
+struct BlockDef { int k, s, e, cin, cout; };
+static const BlockDef B0_BLOCKS[16] = {
+    {3, 1, 1, 32, 16},  {3, 2, 6, 16, 24},  {3, 1, 6, 24, 24},   {5, 2, 6, 24, 40},
+    {5, 1, 6, 40, 40},  {3, 2, 6, 40, 80},  {3, 1, 6, 80, 80},   {3, 1, 6, 80, 80},
+    {5, 1, 6, 80, 112}, {5, 1, 6, 112, 112}, {5, 1, 6, 112, 112}, {5, 2, 6, 112, 192},
+    {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {3, 1, 6, 192, 320}};
+static const int STEM_CH = 32, HEAD_IN = 320, FEAT = 1280, IMG = 224;
+
+static void same_pad(int size, int k, int s, int* before, int* out)
+{
+    *out = (size + s - 1) / s;
+    int pad = (*out - 1) * s + k - size;
+    if (pad < 0) pad = 0;
+    *before = pad / 2;
+}
+
+// A 1x1 convolution packed for pw_gemm_kernel
+struct PwLayer {
+    int N = 0, K = 0, Kp = 0, nt = 0, n_chunks = 0;
+    _Float16* w = nullptr;  // device [n_chunks*16*nt][Kp]
+    float* b = nullptr;     // device [n_chunks*16*nt]
+};
+
+static int pick_nt(int N)
+{
+    const int tiles = (N + 15) / 16;
+    for (int nt = 8; nt >= 1; --nt)
+        if (tiles % nt == 0) return nt;
+    return 1;
+}
+
+struct BlockW {
+    BlockDef d;
+    int H = 0, Ho = 0, ce = 0, cs = 0, pad = 0;
+    bool has_expand = false, skip = false;
+    PwLayer expand, project;
+    float *dw_w = nullptr, *dw_b = nullptr;                    // [k*k][ce], [ce]
+    float *se_wr = nullptr, *se_br = nullptr, *se_we = nullptr, *se_be = nullptr;
+    // depthwise launch geometry
+    int tw = 0, CG = 0, S = 0, iters = 0, parts = 0;
+};
+
+struct Saved {
+    void* dev = nullptr;
+    size_t bytes = 0;
+    size_t elems = 0;
+    bool is_half = true;
+};
+
+struct mmc_backbone {
+    int device = 0, max_batch = 0;
+    _Float16* stem_w = nullptr;
+    float *stem_b = nullptr, *stem_pad = nullptr;
+    BlockW blk[16];
+    PwLayer head;
+    // workspace
+    _Float16 *act0 = nullptr, *act1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
+    float *pool_part = nullptr, *gate = nullptr;
+    uint8_t* in_stage = nullptr;
+    float* out_stage = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<void*> allocs;
+    bool keep = false;
+    std::map<std::string, Saved> saved;
+    int last_n = 0;
+};
+
+struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+struct Prof { std::vector<ProfEntry> entries; };
+
+// ------------------------------------------------------------------------------------------
+// blob parsing: header{magic,version,arch,n_tensors} + table{offset,nbytes} + fp32 tensors
+// ------------------------------------------------------------------------------------------
+struct BlobReader {
+    const uint8_t* base;
+    size_t nbytes;
+    uint32_t n_tensors;
+    const uint64_t* table;
+    uint32_t next = 0;
+    const float* take(size_t n_floats, const char* what, int* err)
+    {
+        if (next >= n_tensors) { *err = fail(MMC_ERR_WEIGHTS, "weights blob ended before %s", what); return nullptr; }
+        const uint64_t off = table[2 * next], nb = table[2 * next + 1];
+        if (off + nb > nbytes || nb != n_floats * sizeof(float)) {
+            *err = fail(MMC_ERR_WEIGHTS, "tensor %u (%s): expected %zu bytes, blob has %llu", next, what,
+                        n_floats * sizeof(float), (unsigned long long)nb);
+            return nullptr;
+        }
+        ++next;
+        return reinterpret_cast<const float*>(base + off);
+    }
+};
+
+template <typename T>
+static int dev_alloc(mmc_backbone* bb, T** p, size_t count)
+{
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, count * sizeof(T) + 256);  // +256: vector tail reads stay in-bounds
+    if (e != hipSuccess) return fail(MMC_ERR_NOMEM, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+    bb->allocs.push_back(d);
+    bb->ws_bytes += count * sizeof(T);
+    *p = reinterpret_cast<T*>(d);
+    return 0;
+}
+
+template <typename T>
+static int dev_upload(mmc_backbone* bb, T** p, const std::vector<T>& host)
+{
+    int r = dev_alloc(bb, p, host.size());
+    if (r) return r;
+    HIP_TRY(hipMemcpy(*p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Pack a natural [N][K] fp32 1x1-conv weight into the row-permuted, zero-padded fp16 layout of
+// pw_gemm_kernel: packed row (chunk*16nt + t*16 + 4q + j) <- channel (chunk*16nt + q*4nt + 4t + j).
+static int pack_pw(mmc_backbone* bb, PwLayer* L, const float* w, const float* b, int N, int K, int force_nt)
+{
+    L->N = N;
+    L->K = K;
+    L->Kp = (K + 31) / 32 * 32;
+    L->nt = force_nt > 0 ? force_nt : pick_nt(N);
+    const int cw = 16 * L->nt;
+    L->n_chunks = (N + cw - 1) / cw;
+    const int Np = L->n_chunks * cw;
+    std::vector<_Float16> wp((size_t)Np * L->Kp, (_Float16)0.0f);
+    std::vector<float> bp(Np, 0.0f);
+    for (int ch = 0; ch < L->n_chunks; ++ch)
+        for (int t = 0; t < L->nt; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < 4; ++j) {
+                    const int prow = ch * cw + t * 16 + 4 * q + j;
+                    const int c = ch * cw + q * 4 * L->nt + 4 * t + j;
+                    if (c >= N) continue;
+                    for (int k = 0; k < K; ++k) wp[(size_t)prow * L->Kp + k] = (_Float16)w[(size_t)c * K + k];
+                }
+    for (int c = 0; c < N; ++c) bp[c] = b[c];
+    int r = dev_upload(bb, &L->w, wp);
+    if (r) return r;
+    return dev_upload(bb, &L->b, bp);
+}
+
+extern "C" void mmc_backbone_destroy(mmc_backbone* bb)
+{
+    if (!bb) return;
+    hipSetDevice(bb->device);
+    for (void* p : bb->allocs) hipFree(p);
+    for (auto& kv : bb->saved) hipFree(kv.second.dev);
+    delete bb;
+}
+
+extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device, int max_batch,
+                                   mmc_backbone** out)
+{
+    if (!out) return fail(MMC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!packed || nbytes < 16) return fail(MMC_ERR_WEIGHTS, "weights blob is empty");
+    if (arch != MMC_ARCH_B0) return fail(MMC_ERR_ARG, "unsupported arch %d (only MMC_ARCH_B0)", arch);
+    if (max_batch < 1 || max_batch > 4096) return fail(MMC_ERR_ARG, "max_batch %d out of range [1,4096]", max_batch);
+    const uint8_t* base = static_cast<const uint8_t*>(packed);
+    uint32_t hdr[4];
+    memcpy(hdr, base, 16);
+    if (memcmp(base, "MMCW", 4) != 0) return fail(MMC_ERR_WEIGHTS, "bad magic in weights blob");
+    if (hdr[1] != 1) return fail(MMC_ERR_WEIGHTS, "weights blob version %u, expected 1", hdr[1]);
+    if ((int)hdr[2] != arch) return fail(MMC_ERR_WEIGHTS, "weights blob arch %u != requested %d", hdr[2], arch);
+    const uint32_t nt = hdr[3];
+    if (16 + (size_t)nt * 16 > nbytes) return fail(MMC_ERR_WEIGHTS, "weights blob truncated (table)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MMC_ERR_HIP, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MMC_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mmc_backbone* bb = new mmc_backbone();
+    bb->device = device;
+    bb->max_batch = max_batch;
+    const char* keep = getenv("MMC_KEEP_ACTIVATIONS");
+    bb->keep = keep && keep[0] == '1';
+    std::vector<uint64_t> table(2 * (size_t)nt);
+    memcpy(table.data(), base + 16, (size_t)nt * 16);
+    BlobReader rd{base, nbytes, nt, table.data()};
+    int err = 0;
+#define TAKE(var, n, what)                         \
+    const float* var = rd.take((n), what, &err);   \
+    if (!var) { mmc_backbone_destroy(bb); return err; }
+#define TRY_OR_FREE(expr)                          \
+    do { int r__ = (expr); if (r__) { mmc_backbone_destroy(bb); return r__; } } while (0)
+
+    // ---- stem: [32][27] folded (ky,kx,c), bias[32], padval[3] ----
+    {
+        TAKE(w, (size_t)STEM_CH * 27, "stem.weight");
+        TAKE(b, STEM_CH, "stem.bias");
+        TAKE(pv, 3, "stem.padval");
+        std::vector<_Float16> wp(32 * 32, (_Float16)0.0f);
+        for (int t = 0; t < 2; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < 4; ++j) {
+                    const int prow = t * 16 + 4 * q + j;
+                    const int c = q * 8 + 4 * t + j;
+                    const float* wc = w + (size_t)c * 27;
+                    for (int qq = 0; qq < 3; ++qq)           // kernel row qq, bytes 0..7 of its 9-byte run
+                        for (int jj = 0; jj < 8; ++jj) wp[prow * 32 + qq * 8 + jj] = (_Float16)wc[qq * 9 + jj];
+                    for (int jj = 0; jj < 3; ++jj) wp[prow * 32 + 24 + jj] = (_Float16)wc[jj * 9 + 8];
+                }
+        TRY_OR_FREE(dev_upload(bb, &bb->stem_w, wp));
+        TRY_OR_FREE(dev_upload(bb, &bb->stem_b, std::vector<float>(b, b + STEM_CH)));
+        std::vector<float> pvv = {pv[0], pv[1], pv[2], 0.f};
+        TRY_OR_FREE(dev_upload(bb, &bb->stem_pad, pvv));
+    }
+    // ---- blocks ----
+    int H = IMG / 2;
+    size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
+    int max_c = 0;
+    for (int i = 0; i < 16; ++i) {
+        BlockW& B = bb->blk[i];
+        B.d = B0_BLOCKS[i];
+        B.H = H;
+        B.ce = B.d.cin * B.d.e;
+        B.cs = B.d.cin / 4 > 1 ? B.d.cin / 4 : 1;
+        B.has_expand = B.d.e != 1;
+        B.skip = B.d.s == 1 && B.d.cin == B.d.cout;
+        same_pad(H, B.d.k, B.d.s, &B.pad, &B.Ho);
+        char nm[64];
+        if (B.has_expand) {
+            snprintf(nm, sizeof nm, "b%d.expand", i);
+            TAKE(w, (size_t)B.ce * B.d.cin, nm);
+            TAKE(b, B.ce, nm);
+            TRY_OR_FREE(pack_pw(bb, &B.expand, w, b, B.ce, B.d.cin, 0));
+        }
+        {
+            snprintf(nm, sizeof nm, "b%d.dw", i);
+            TAKE(w, (size_t)B.ce * B.d.k * B.d.k, nm);  // [ce][k][k]
+            TAKE(b, B.ce, nm);
+            const int kk = B.d.k * B.d.k;
+            std::vector<float> wt((size_t)kk * B.ce);
+            for (int c = 0; c < B.ce; ++c)
+                for (int t = 0; t < kk; ++t) wt[(size_t)t * B.ce + c] = w[(size_t)c * kk + t];
+            TRY_OR_FREE(dev_upload(bb, &B.dw_w, wt));
+            TRY_OR_FREE(dev_upload(bb, &B.dw_b, std::vector<float>(b, b + B.ce)));
+        }
+        {
+            snprintf(nm, sizeof nm, "b%d.se", i);
+            TAKE(wr, (size_t)B.cs * B.ce, nm);
+            TAKE(br, B.cs, nm);
+            TAKE(we, (size_t)B.ce * B.cs, nm);
+            TAKE(be, B.ce, nm);
+            TRY_OR_FREE(dev_upload(bb, &B.se_wr, std::vector<float>(wr, wr + (size_t)B.cs * B.ce)));
+            TRY_OR_FREE(dev_upload(bb, &B.se_br, std::vector<float>(br, br + B.cs)));
+            TRY_OR_FREE(dev_upload(bb, &B.se_we, std::vector<float>(we, we + (size_t)B.ce * B.cs)));
+            TRY_OR_FREE(dev_upload(bb, &B.se_be, std::vector<float>(be, be + B.ce)));
+        }
+        {
+            snprintf(nm, sizeof nm, "b%d.project", i);
+            TAKE(w, (size_t)B.d.cout * B.ce, nm);
+            TAKE(b, B.d.cout, nm);
+            TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, 0));
+        }
+        // depthwise geometry
+        B.tw = (B.Ho % 4 == 0) ? 4 : (B.Ho % 7 == 0 && B.Ho <= 7 ? 7 : 2);
+        B.CG = B.ce / 8;
+        B.S = 256 / B.CG > 0 ? 256 / B.CG : 1;
+        const int strips = B.Ho * (B.Ho / B.tw);
+        const int passes = (strips + B.S - 1) / B.S;
+        B.iters = passes >= 8 ? 4 : 1;
+        B.parts = (passes + B.iters - 1) / B.iters;
+        if ((size_t)H * H * B.ce > max_exp && B.has_expand) max_exp = (size_t)H * H * B.ce;
+        if ((size_t)B.Ho * B.Ho * B.ce > max_dw) max_dw = (size_t)B.Ho * B.Ho * B.ce;
+        if ((size_t)B.Ho * B.Ho * B.d.cout > max_act) max_act = (size_t)B.Ho * B.Ho * B.d.cout;
+        if ((size_t)B.parts * B.ce > max_pool) max_pool = (size_t)B.parts * B.ce;
+        if (B.ce > max_c) max_c = B.ce;
+        H = B.Ho;
+    }
+    {
+        TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
+        TAKE(b, FEAT, "head.bias");
+        TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 8));
+    }
+    if (rd.next != nt) {
+        mmc_backbone_destroy(bb);
+        return fail(MMC_ERR_WEIGHTS, "weights blob has %u tensors, expected %u", nt, rd.next);
+    }
+    const size_t mb = (size_t)max_batch;
+    TRY_OR_FREE(dev_alloc(bb, &bb->act0, mb * max_act));
+    TRY_OR_FREE(dev_alloc(bb, &bb->act1, mb * max_act));
+    TRY_OR_FREE(dev_alloc(bb, &bb->expbuf, mb * max_exp));
+    TRY_OR_FREE(dev_alloc(bb, &bb->dwbuf, mb * max_dw));
+    TRY_OR_FREE(dev_alloc(bb, &bb->pool_part, mb * max_pool));
+    TRY_OR_FREE(dev_alloc(bb, &bb->gate, mb * (size_t)max_c));
+    TRY_OR_FREE(dev_alloc(bb, &bb->in_stage, mb * (size_t)IMG * IMG * 3));
+    TRY_OR_FREE(dev_alloc(bb, &bb->out_stage, mb * (size_t)FEAT));
+#undef TAKE
+#undef TRY_OR_FREE
+    *out = bb;
+    return MMC_OK;
+}
+
+extern "C" int mmc_feature_dim(const mmc_backbone* bb) { return bb ? FEAT : 0; }
+extern "C" int mmc_backbone_max_batch(const mmc_backbone* bb) { return bb ? bb->max_batch : 0; }
+extern "C" size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb) { return bb ? bb->ws_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------
+// the launch schedule for one pass over n <= max_batch resident patches
+// ------------------------------------------------------------------------------------------
+static int save_act(mmc_backbone* bb, const char* name, const void* dev, size_t elems, bool is_half, hipStream_t st)
+{
+    Saved& s = bb->saved[name];
+    const size_t bytes = elems * (is_half ? 2 : 4);
+    if (s.bytes < bytes) {
+        if (s.dev) hipFree(s.dev);
+        HIP_TRY(hipMalloc(&s.dev, bytes));
+        s.bytes = bytes;
+    }
+    s.elems = elems;
+    s.is_half = is_half;
+    HIP_TRY(hipMemcpyAsync(s.dev, dev, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int epi, const float* gate, int HW,
+                    const _Float16* res, float* gap_out, hipStream_t st)
+{
+    GemmArgs a{};
+    a.X = X; a.M = M; a.K = L.K; a.Wp = L.w; a.Kp = L.Kp; a.bias = L.b; a.Y = Y; a.N = L.N;
+    a.nt = L.nt; a.n_chunks = L.n_chunks; a.epi = epi; a.gate = gate; a.HW = HW; a.res = res;
+    a.gap_out = gap_out; a.inv_hw = 1.0f / (float)HW;
+    // two row fragments per wave when that still leaves >= ~4 workgroups per CU
+    const long wgs2 = ((long)M + 127) / 128 * L.n_chunks;
+    a.mt = wgs2 >= 1024 ? 2 : 1;
+    return launch_pw_gemm(a, st);
+}
+
+static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
+{
+#define STEP(nm, expr)                                                                  \
+    do {                                                                                \
+        ProfEntry pe_;                                                                  \
+        if (prof) {                                                                     \
+            pe_.name = (nm);                                                            \
+            HIP_TRY(hipEventCreate(&pe_.e0));                                           \
+            HIP_TRY(hipEventCreate(&pe_.e1));                                           \
+            HIP_TRY(hipEventRecord(pe_.e0, st));                                        \
+        }                                                                               \
+        KTRY(expr);                                                                     \
+        if (prof) {                                                                     \
+            HIP_TRY(hipEventRecord(pe_.e1, st));                                        \
+            prof->entries.push_back(pe_);                                               \
+        }                                                                               \
+    } while (0)
+    char nm[64];
+    _Float16* x = bb->act0;
+    _Float16* y = bb->act1;
+    STEP("stem", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
+    if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
+    for (int i = 0; i < 16; ++i) {
+        BlockW& B = bb->blk[i];
+        const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
+        const _Float16* dw_in = x;
+        if (B.has_expand) {
+            snprintf(nm, sizeof nm, "b%d.expand", i);
+            STEP(nm, run_gemm(B.expand, x, n * HWi, bb->expbuf, EPI_SILU, nullptr, HWi, nullptr, nullptr, st));
+            if (bb->keep) { int r = save_act(bb, nm, bb->expbuf, (size_t)n * HWi * B.ce, true, st); if (r) return r; }
+            dw_in = bb->expbuf;
+        }
+        DwArgs d{};
+        d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = bb->dwbuf; d.pool_part = bb->pool_part;
+        d.B = n; d.H = B.H; d.W = B.H; d.C = B.ce; d.Ho = B.Ho; d.Wo = B.Ho; d.pad_t = B.pad; d.pad_l = B.pad;
+        d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts;
+        snprintf(nm, sizeof nm, "b%d.dw", i);
+        STEP(nm, launch_dwconv(d, st));
+        if (bb->keep) { int r = save_act(bb, nm, bb->dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
+        snprintf(nm, sizeof nm, "b%d.gate", i);
+        STEP(nm, launch_se_gate(bb->pool_part, B.parts, n, B.ce, B.cs, 1.0f / (float)HWo, B.se_wr, B.se_br, B.se_we,
+                                B.se_be, bb->gate, st));
+        if (bb->keep) { int r = save_act(bb, nm, bb->gate, (size_t)n * B.ce, false, st); if (r) return r; }
+        snprintf(nm, sizeof nm, "b%d.project", i);
+        STEP(nm, run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
+        snprintf(nm, sizeof nm, "b%d.out", i);
+        if (bb->keep) { int r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st); if (r) return r; }
+        _Float16* t = x; x = y; y = t;
+    }
+    const int HWh = bb->blk[15].Ho * bb->blk[15].Ho;
+    STEP("head", run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
+    bb->last_n = n;
+#undef STEP
+    return 0;
+}
+
+extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
+                                    unsigned flags, void* hip_stream)
+{
+    if (!bb) return fail(MMC_ERR_ARG, "backbone handle is NULL");
+    if (n < 0) return fail(MMC_ERR_ARG, "n = %lld is negative", (long long)n);
+    if (n == 0) return MMC_OK;
+    if (!patches || !out_features) return fail(MMC_ERR_ARG, "patches/out_features is NULL");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(bb->device));
+    const size_t psz = (size_t)IMG * IMG * 3;
+    const uint8_t* in = static_cast<const uint8_t*>(patches);
+    for (int64_t off = 0; off < n; off += bb->max_batch) {
+        const int cur = (int)((n - off) < bb->max_batch ? (n - off) : bb->max_batch);
+        const uint8_t* pin = in + (size_t)off * psz;
+        if (flags & MMC_IN_HOST) {
+            HIP_TRY(hipMemcpyAsync(bb->in_stage, pin, (size_t)cur * psz, hipMemcpyHostToDevice, st));
+            pin = bb->in_stage;
+        }
+        float* pout = (flags & MMC_OUT_HOST) ? bb->out_stage : out_features + (size_t)off * FEAT;
+        int r = forward_pass(bb, pin, cur, pout, st, nullptr);
+        if (r) return r;
+        if (flags & MMC_OUT_HOST)
+            HIP_TRY(hipMemcpyAsync(out_features + (size_t)off * FEAT, bb->out_stage, (size_t)cur * FEAT * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+    }
+    if (flags & MMC_OUT_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MMC_OK;
+}
+
+extern "C" int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, float* out, size_t capacity,
+                                            size_t* n_written)
+{
+    if (!bb || !name || !out) return fail(MMC_ERR_ARG, "NULL argument");
+    if (!bb->keep) return fail(MMC_ERR_ARG, "activations are not kept: set MMC_KEEP_ACTIVATIONS=1 before create");
+    auto it = bb->saved.find(name);
+    if (it == bb->saved.end()) return fail(MMC_ERR_ARG, "no saved activation named '%s'", name);
+    const Saved& s = it->second;
+    if (s.elems > capacity) return fail(MMC_ERR_ARG, "'%s' has %zu elements, capacity %zu", name, s.elems, capacity);
+    HIP_TRY(hipSetDevice(bb->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (s.is_half) {
+        std::vector<_Float16> tmp(s.elems);
+        HIP_TRY(hipMemcpy(tmp.data(), s.dev, s.elems * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < s.elems; ++i) out[i] = (float)tmp[i];
+    } else {
+        HIP_TRY(hipMemcpy(out, s.dev, s.elems * 4, hipMemcpyDeviceToHost));
+    }
+    if (n_written) *n_written = s.elems;
+    return MMC_OK;
+}
+
+extern "C" int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, float* out_features_dev,
+                                    void* hip_stream, char (*names)[48], float* ms, int* launches, int cap, int* n_out)
+{
+    if (!bb || !patches_dev || !out_features_dev || !names || !ms || !n_out)
+        return fail(MMC_ERR_ARG, "NULL argument");
+    if (n < 1 || n > bb->max_batch) return fail(MMC_ERR_ARG, "n must be in [1, max_batch]");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(bb->device));
+    Prof prof;
+    int r = forward_pass(bb, static_cast<const uint8_t*>(patches_dev), (int)n, out_features_dev, st, &prof);
+    if (r) return r;
+    HIP_TRY(hipStreamSynchronize(st));
+    int cnt = 0;
+    for (auto& e : prof.entries) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e.e0, e.e1));
+        hipEventDestroy(e.e0);
+        hipEventDestroy(e.e1);
+        if (cnt < cap) {
+            snprintf(names[cnt], 48, "%s", e.name.c_str());
+            ms[cnt] = t;
+            if (launches) launches[cnt] = 1;
+            ++cnt;
+        }
+    }
+    *n_out = cnt;
+    return MMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// crop front-end
+// ------------------------------------------------------------------------------------------
+extern "C" int mmc_crop_patches(const void* image, int height, int width, const int32_t* rowcols, int64_t n,
+                                void* patches_out_dev, unsigned flags, int device, void* hip_stream)
+{
+    if (!image || !rowcols || !patches_out_dev) return fail(MMC_ERR_ARG, "NULL argument");
+    if (n < 0 || n > 65535) return fail(MMC_ERR_ARG, "n = %lld out of range [0,65535]", (long long)n);
+    if (n == 0) return MMC_OK;
+    if (height <= IMG || width <= IMG)
+        return fail(MMC_ERR_ARG, "image %dx%d must exceed the crop size %d in both dimensions", height, width, IMG);
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(device));
+    const uint8_t* img = static_cast<const uint8_t*>(image);
+    const int32_t* rc = rowcols;
+    void* tmp_img = nullptr;
+    void* tmp_rc = nullptr;
+    if (flags & MMC_IN_HOST) {
+        for (int64_t i = 0; i < n; ++i) {
+            const int r = rowcols[2 * i], c = rowcols[2 * i + 1];
+            if (r < 0 || r >= height || c < 0 || c >= width)
+                return fail(MMC_ERR_ARG, "point %lld (%d,%d) outside the %dx%d image", (long long)i, r, c, height, width);
+        }
+        const size_t ib = (size_t)height * width * 3;
+        HIP_TRY(hipMalloc(&tmp_img, ib));
+        HIP_TRY(hipMalloc(&tmp_rc, (size_t)n * 8));
+        HIP_TRY(hipMemcpyAsync(tmp_img, image, ib, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(tmp_rc, rowcols, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        img = static_cast<const uint8_t*>(tmp_img);
+        rc = static_cast<const int32_t*>(tmp_rc);
+    }
+    int r = launch_crop(img, height, width, rc, (int)n, static_cast<uint8_t*>(patches_out_dev), st);
+    if (tmp_img) {
+        hipStreamSynchronize(st);
+        hipFree(tmp_img);
+        hipFree(tmp_rc);
+    }
+    if (r) return fail(MMC_ERR_HIP, "crop kernel launch failed (%d)", r);
+    return MMC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// calibrated MLP head
+// ------------------------------------------------------------------------------------------
+struct mmc_head {
+    int device = 0, n_layers = 0, K = 0, input_dim = 0, in_pad = 0;
+    std::vector<int> dims_pad;        // padded widths (multiples of 4), last = K (unpadded)
+    std::vector<float*> W, b;         // device
+    float *a = nullptr, *bc = nullptr;
+    float *buf0 = nullptr, *buf1 = nullptr, *in_stage = nullptr, *proba_stage = nullptr;
+    int32_t* arg_stage = nullptr;
+    int64_t cap_rows = 0;
+};
+
+extern "C" void mmc_head_destroy(mmc_head* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    for (float* p : h->W) hipFree(p);
+    for (float* p : h->b) hipFree(p);
+    hipFree(h->a); hipFree(h->bc); hipFree(h->buf0); hipFree(h->buf1);
+    hipFree(h->in_stage); hipFree(h->proba_stage); hipFree(h->arg_stage);
+    delete h;
+}
+
+extern "C" int mmc_head_create(const float* const* W, const float* const* b, const int* dims, int n_layers,
+                               const float* a, const float* bcal, int K, int device, mmc_head** out)
+{
+    if (!out) return fail(MMC_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!W || !b || !dims || !a || !bcal) return fail(MMC_ERR_ARG, "NULL argument");
+    if (n_layers < 1 || n_layers > 16) return fail(MMC_ERR_ARG, "n_layers %d out of range [1,16]", n_layers);
+    if (K <= 2) return fail(MMC_ERR_ARG, "CalibratedHead only supports the multiclass (K > 2) path; got K=%d", K);
+    if (dims[n_layers] != K) return fail(MMC_ERR_ARG, "dims[n_layers]=%d != K=%d", dims[n_layers], K);
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1) return fail(MMC_ERR_ARG, "dims[%d]=%d must be positive", l, dims[l]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(MMC_ERR_HIP, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(MMC_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    mmc_head* h = new mmc_head();
+    h->device = device; h->n_layers = n_layers; h->K = K; h->input_dim = dims[0];
+    h->dims_pad.resize(n_layers + 1);
+    for (int l = 0; l <= n_layers; ++l) h->dims_pad[l] = (l == n_layers) ? dims[l] : (dims[l] + 3) / 4 * 4;
+    h->in_pad = h->dims_pad[0];
+    for (int l = 0; l < n_layers; ++l) {
+        const int kin = dims[l], kp = h->dims_pad[l], nout = dims[l + 1], np = h->dims_pad[l + 1];
+        std::vector<float> wp((size_t)np * kp, 0.f), bp(np, 0.f);
+        for (int n = 0; n < nout; ++n) {
+            memcpy(&wp[(size_t)n * kp], W[l] + (size_t)n * kin, (size_t)kin * sizeof(float));
+            bp[n] = b[l][n];
+        }
+        float *dw = nullptr, *db = nullptr;
+        if (hipMalloc((void**)&dw, wp.size() * 4 + 256) != hipSuccess || hipMalloc((void**)&db, bp.size() * 4 + 256) != hipSuccess) {
+            mmc_head_destroy(h);
+            return fail(MMC_ERR_NOMEM, "hipMalloc failed for head layer %d", l);
+        }
+        h->W.push_back(dw); h->b.push_back(db);
+        hipMemcpy(dw, wp.data(), wp.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(db, bp.data(), bp.size() * 4, hipMemcpyHostToDevice);
+    }
+    if (hipMalloc((void**)&h->a, K * 4 + 256) != hipSuccess || hipMalloc((void**)&h->bc, K * 4 + 256) != hipSuccess) {
+        mmc_head_destroy(h);
+        return fail(MMC_ERR_NOMEM, "hipMalloc failed for calibration parameters");
+    }
+    hipMemcpy(h->a, a, K * 4, hipMemcpyHostToDevice);
+    hipMemcpy(h->bc, bcal, K * 4, hipMemcpyHostToDevice);
+    *out = h;
+    return MMC_OK;
+}
+
+extern "C" int mmc_head_input_dim(const mmc_head* h) { return h ? h->input_dim : 0; }
+extern "C" int mmc_head_num_classes(const mmc_head* h) { return h ? h->K : 0; }
+
+static int head_reserve(mmc_head* h, int64_t rows)
+{
+    if (rows <= h->cap_rows) return 0;
+    hipFree(h->buf0); hipFree(h->buf1); hipFree(h->in_stage); hipFree(h->proba_stage); hipFree(h->arg_stage);
+    h->buf0 = h->buf1 = h->in_stage = h->proba_stage = nullptr; h->arg_stage = nullptr; h->cap_rows = 0;
+    int wmax = h->K;
+    for (int d : h->dims_pad) wmax = d > wmax ? d : wmax;
+    const size_t nb = (size_t)rows * wmax * 4 + 256;
+    HIP_TRY(hipMalloc((void**)&h->buf0, nb));
+    HIP_TRY(hipMalloc((void**)&h->buf1, nb));
+    HIP_TRY(hipMalloc((void**)&h->in_stage, (size_t)rows * h->in_pad * 4 + 256));
+    HIP_TRY(hipMalloc((void**)&h->proba_stage, (size_t)rows * h->K * 4 + 256));
+    HIP_TRY(hipMalloc((void**)&h->arg_stage, (size_t)rows * 4 + 256));
+    h->cap_rows = rows;
+    return 0;
+}
+
+extern "C" int mmc_head_predict(mmc_head* h, const float* feats, int64_t n, float* proba, int32_t* argmax,
+                                unsigned flags, void* hip_stream)
+{
+    if (!h) return fail(MMC_ERR_ARG, "head handle is NULL");
+    if (n < 0) return fail(MMC_ERR_ARG, "n = %lld is negative", (long long)n);
+    if (n == 0) return MMC_OK;
+    if (!feats || !proba) return fail(MMC_ERR_ARG, "feats/proba is NULL");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t chunk = 65536;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int cur = (int)((n - off) < chunk ? (n - off) : chunk);
+        int r = head_reserve(h, cur);
+        if (r) return r;
+        const float* x = feats + (size_t)off * h->input_dim;
+        const hipMemcpyKind kin = (flags & MMC_IN_HOST) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+        if ((flags & MMC_IN_HOST) || h->in_pad != h->input_dim) {
+            if (h->in_pad != h->input_dim) HIP_TRY(hipMemsetAsync(h->in_stage, 0, (size_t)cur * h->in_pad * 4, st));
+            HIP_TRY(hipMemcpy2DAsync(h->in_stage, (size_t)h->in_pad * 4, x, (size_t)h->input_dim * 4,
+                                     (size_t)h->input_dim * 4, cur, kin, st));
+            x = h->in_stage;
+        }
+        float* pa = h->buf0;
+        float* pb = h->buf1;
+        for (int l = 0; l < h->n_layers; ++l) {
+            const bool last = l == h->n_layers - 1;
+            KTRY(launch_mlp_layer(x, cur, h->dims_pad[l], h->W[l], h->b[l], pa, h->dims_pad[l + 1], !last, st));
+            x = pa;
+            float* t = pa; pa = pb; pb = t;
+        }
+        float* pout = (flags & MMC_OUT_HOST) ? h->proba_stage : proba + (size_t)off * h->K;
+        int32_t* aout = argmax ? ((flags & MMC_OUT_HOST) ? h->arg_stage : argmax + off) : nullptr;
+        KTRY(launch_calibrate(x, cur, h->K, h->a, h->bc, pout, aout, st));
+        if (flags & MMC_OUT_HOST) {
+            HIP_TRY(hipMemcpyAsync(proba + (size_t)off * h->K, pout, (size_t)cur * h->K * 4, hipMemcpyDeviceToHost, st));
+            if (argmax) HIP_TRY(hipMemcpyAsync(argmax + off, aout, (size_t)cur * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    return MMC_OK;
+}

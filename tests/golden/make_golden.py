@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures.  Run ONCE in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Head fixtures come from the REFERENCE ITSELF, imported from /root/reference
+(``mermaid_classifier.pyspacer.inference.head`` / ``.loader`` /
+``.torch_classifier`` and the reference's own test fixture
+``tests/pyspacer/_calibrated_model_fixture.py``): inputs, parameters and the
+outputs of its ``CalibratedHead`` / ``Predictor`` / sklearn ``predict_proba``.
+``export_artifact`` itself cannot run here (sklearn pin 1.5.2 vs 1.7.2 installed,
+and ``importlib.metadata.version('pyspacer')`` -- SURVEY 8c), so ``model.pt`` /
+``model.json`` are written by the same calls it makes (export.py:52-57, 72-92).
+
+Backbone fixtures are SELF-ORACLE (parity unpinned: pyspacer is absent): the
+synthetic-weights BN statistics and the oracle's fp32 features on the seed-42
+patches of scripts/build_feature_bucket.py:469-473 and on image-like patches.
+
+Nothing from /root/reference is copied: only inputs/outputs (data) are stored.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import efficientnet_b0_ref as bb  # noqa: E402
+from oracle import pyspacer_ref  # noqa: E402
+
+
+def backbone():
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = bb.make_synthetic_state_dict(seed=0, bn_stats=None)
+    np.savez_compressed(HERE / "synth_bn_stats.npz", **bb.bn_stats_of(sd))
+    net = bb.EfficientNetB0Ref(sd)
+    noise = bb.synthetic_patches(8, seed=42)
+    natural = bb.natural_patches(8, seed=7)
+    f_noise = bb.patches_to_features(net, noise, batch_size=10)
+    f_nat = bb.patches_to_features(net, natural, batch_size=10)
+    # per-layer checksums on 2 patches (mean, mean|x|, max|x| of every tapped tensor)
+    taps = {}
+    net.extract_features(bb.transformation(noise[:2]), taps=taps)
+    names = sorted(taps)
+    sums = np.array([[taps[k].mean().item(), taps[k].abs().mean().item(), taps[k].abs().max().item()] for k in names],
+                    dtype=np.float64)
+    # config-1 geometry, scaled down: one synthetic image, the CSV's 5x5 grid scaled to it
+    rng = np.random.default_rng(42)
+    image = rng.integers(0, 255, (696, 928, 3), dtype=np.uint8)
+    rowcols = [(r, c) for r in (0, 116, 348, 580, 695) for c in (0, 232, 464, 927)][:10]
+    f_img = pyspacer_ref.extract(net, image, rowcols, batch_size=10)
+    np.savez_compressed(HERE / "backbone_features.npz", noise8=f_noise, natural8=f_nat,
+                        tap_names=np.array(names), tap_sums=sums,
+                        image_rowcols=np.array(rowcols, dtype=np.int64), image_features=f_img)
+    print("backbone fixtures written", f_noise.shape, f_nat.shape, f_img.shape)
+
+
+def head():
+    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, "/root/reference/tests")
+    from mermaid_classifier.pyspacer.inference import SCHEMA_VERSION, TASK_NAME  # type: ignore
+    from mermaid_classifier.pyspacer.inference.head import build_calibrated_head  # type: ignore
+    from mermaid_classifier.pyspacer.inference.loader import load_predictor  # type: ignore
+    from mermaid_classifier.pyspacer.torch_classifier import TorchMLPClassifier  # type: ignore
+    from pyspacer._calibrated_model_fixture import make_calibrated_model  # type: ignore
+    from sklearn.calibration import CalibratedClassifierCV, _fit_calibrator
+    import sklearn
+
+    def export(model, out_dir: Path, input_dim: int):
+        out_dir.mkdir(parents=True, exist_ok=True)
+        h = build_calibrated_head(model)
+        h.eval()
+        frozen = torch.jit.freeze(torch.jit.script(h))
+        torch.jit.save(frozen, str(out_dir / "model.pt"))
+        manifest = {
+            "schema_version": SCHEMA_VERSION, "task": TASK_NAME,
+            "classes": model.classes_.tolist(), "input_dim": int(input_dim),
+            "config": {"patch_size": 224},
+            "trained_with": {"torch": torch.__version__, "sklearn": sklearn.__version__, "pyspacer": "0.14.0"},
+        }
+        (out_dir / "model.json").write_text(json.dumps(manifest, indent=2))
+        return h
+
+    def dump(tag: str, model, h, X, out_dir: Path):
+        with torch.no_grad():
+            eager = h(torch.from_numpy(X.astype(np.float32))).numpy()
+        pred = load_predictor(out_dir / "model.pt", out_dir / "model.json")
+        got = pred.predict_proba(X)
+        sk = model.predict_proba(X)
+        print(tag, "max|head-sklearn|", np.abs(eager - sk).max(), "max|predictor-eager|", np.abs(got - eager).max())
+        arrs = {"X": X.astype(np.float32), "proba_head_f32": eager.astype(np.float32),
+                "proba_predictor_f64": got, "proba_sklearn_f64": sk,
+                "a": h.a.numpy(), "b": h.b.numpy(), "n_layers": np.array(len(h.linears))}
+        for i, lin in enumerate(h.linears):
+            arrs[f"W{i}"] = lin.weight.detach().numpy()
+            arrs[f"b{i}"] = lin.bias.detach().numpy()
+        return arrs
+
+    # (1) the reference's own small test fixture: 8 -> 16 -> 5
+    model, X = make_calibrated_model()
+    d = HERE / "head_fixture"
+    h = export(model, d, X.shape[1])
+    np.savez_compressed(HERE / "head_fixture_io.npz", **dump("fixture", model, h, X, d))
+
+    # (2) production-shaped head: 1280 -> (500,300,100) -> 108 (trainer.py:118-123), seed 0
+    rng = np.random.default_rng(0)
+    k, nf, ns = 108, 1280, 6000
+    classes = np.array([f"ba{i:03d}::gf{i:03d}" for i in range(k)])
+    base = rng.normal(0.4, 0.35, size=(1, nf))
+    centers = np.abs(base + 0.10 * rng.normal(size=(k, nf))).astype(np.float32)
+    yi = rng.integers(0, k, size=ns)
+    Xb = np.abs(centers[yi] + rng.normal(0, 0.25, size=(ns, nf))).astype(np.float32)
+    y = classes[yi]
+    clf = TorchMLPClassifier(hidden_layer_sizes=(500, 300, 100), learning_rate_init=1e-3, random_state=0)
+    for _ in range(12):
+        clf.partial_fit(Xb, y, classes=classes.tolist())
+    preds = clf.predict_proba(Xb)
+    inner = _fit_calibrator(clf, preds, y, clf.classes_, method="sigmoid")
+    wrapper = CalibratedClassifierCV(clf, cv="prefit")
+    wrapper.calibrated_classifiers_ = [inner]
+    wrapper.classes_ = clf.classes_
+    d = HERE / "head108"
+    h = export(wrapper, d, nf)
+    # evaluation inputs: held-out samples of the same family (hard + easy rows)
+    yi2 = rng.integers(0, k, size=256)
+    Xe = np.abs(centers[yi2] + rng.normal(0, 0.45, size=(256, nf))).astype(np.float32)
+    arrs = dump("head108", wrapper, h, Xe, d)
+    # weights live in model.pt; keep the io file small
+    small = {k_: v for k_, v in arrs.items() if not (k_.startswith("W") or (k_.startswith("b") and k_[1:].isdigit()))}
+    np.savez_compressed(HERE / "head108_io.npz", **small)
+    acc = (np.argmax(arrs["proba_head_f32"], 1) == yi2).mean()
+    print("head108 held-out accuracy", acc)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["backbone", "head"]
+    if "backbone" in which:
+        backbone()
+    if "head" in which:
+        head()

@@ -1,0 +1,53 @@
+"""-m gpu: per-kernel parity.  Every HBM-resident intermediate of the HIP schedule
+(MMC_KEEP_ACTIVATIONS=1) against the fp32 CPU oracle's tensor of the same name, on the same
+seeded inputs and synthetic weights.  Tolerances are per layer and relative to the tensor's
+RMS: one fp16 rounding of inputs/weights/outputs per layer is ~5e-4; errors accumulate with depth."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kept_backbone(checkpoint_path):
+    os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
+    try:
+        from mermaid_classifier_amd.backbone import Backbone
+        bb = Backbone(str(checkpoint_path), device=0, max_batch=4)
+    finally:
+        os.environ.pop("MMC_KEEP_ACTIVATIONS", None)
+    yield bb
+    bb.close()
+
+
+@pytest.mark.parametrize("kind", ["noise", "natural"])
+def test_every_intermediate_matches_oracle(kept_backbone, oracle_net, kind):
+    from oracle import efficientnet_b0_ref as ref
+    patches = ref.synthetic_patches(3, seed=42) if kind == "noise" else ref.natural_patches(3, seed=7)
+    taps = {}
+    want = oracle_net.extract_features(ref.transformation(patches), taps=taps).numpy()
+    got = kept_backbone.extract(patches)
+    report = []
+    worst = 0.0
+    for name, t in taps.items():
+        if name == "features":
+            continue
+        o = t.numpy()
+        if o.ndim == 4 and name.endswith(".gate"):
+            o = o.reshape(o.shape[0], o.shape[1])
+        elif o.ndim == 4:
+            o = o.transpose(0, 2, 3, 1)  # NCHW -> NHWC
+        g = kept_backbone.read_activation(name, o.size).reshape(o.shape)
+        err = np.sqrt(np.mean((g - o) ** 2)) / (np.sqrt(np.mean(o ** 2)) + 1e-12)
+        mx = np.abs(g - o).max()
+        report.append(f"{name:12s} rel_rms={err:.2e} maxabs={mx:.3e}")
+        worst = max(worst, err)
+    print("\n".join(report))
+    depth_tol = 2e-2 if kind == "noise" else 1e-2
+    assert worst < depth_tol, "\n".join(report)
+    rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
+    print("features rel-L2", rel)
+    assert rel.max() < (1e-2 if kind == "noise" else 1e-3)

@@ -1,0 +1,151 @@
+"""-m gpu: end-to-end parity of the HIP path, called through the C ABI, against the CPU oracle
+and the committed golden fixtures."""
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, cosine, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (fp16 storage/MFMA operands, fp32 accumulation; see DESIGN.md "Numerics"):
+#   image-like patches: per-vector relative L2 < 1e-3   (north_star gate)
+#   seed-42 white-noise patches (the reference's own gate inputs): cosine >= 0.999
+#   (scripts/build_feature_bucket.py:456-457) and relative L2 < 1e-2 (fp16 floor ~5e-3: white
+#   noise through a random-weight net amplifies every rounding; oracle emulation agrees).
+TOL_NATURAL = 1e-3
+TOL_NOISE = 1e-2
+COS_GATE = 0.999
+
+
+@pytest.fixture(scope="module")
+def backbone(checkpoint_path):
+    from mermaid_classifier_amd.backbone import Backbone
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=16)
+    yield bb
+    bb.close()
+
+
+def test_golden_features_noise(backbone, golden_backbone):
+    from oracle import efficientnet_b0_ref as ref
+    got = backbone.extract(ref.synthetic_patches(8, seed=42))
+    want = golden_backbone["noise8"]
+    r, c = rel_l2(got, want), cosine(got, want)
+    print("noise rel-L2", r, "cos", c, "maxabs", np.abs(got - want).max())
+    assert c.min() >= COS_GATE
+    assert r.max() < TOL_NOISE
+
+
+def test_golden_features_natural(backbone, golden_backbone):
+    from oracle import efficientnet_b0_ref as ref
+    got = backbone.extract(ref.natural_patches(8, seed=7))
+    want = golden_backbone["natural8"]
+    r, c = rel_l2(got, want), cosine(got, want)
+    print("natural rel-L2", r, "cos", c, "maxabs", np.abs(got - want).max())
+    assert c.min() >= COS_GATE
+    assert r.max() < TOL_NATURAL
+
+
+def test_batching_is_bitwise_invariant(backbone):
+    """Rows are independent: any split of the same patches gives identical bits (ragged + max-batch)."""
+    from oracle import efficientnet_b0_ref as ref
+    p = ref.natural_patches(19, seed=3)          # 19 > max_batch=16 -> internal chunking, ragged tail
+    whole = backbone.extract(p)
+    parts = np.concatenate([backbone.extract(p[:1]), backbone.extract(p[1:8]), backbone.extract(p[8:])])
+    assert np.array_equal(whole, parts)
+    assert backbone.extract(p[:0]).shape == (0, 1280)
+    again = backbone.extract(p)
+    assert np.array_equal(whole, again)           # deterministic run to run
+
+
+def test_device_resident_path_matches_host_path(backbone):
+    import torch
+    from oracle import efficientnet_b0_ref as ref
+    p = ref.synthetic_patches(5, seed=11)
+    host = backbone.extract(p)
+    dev = backbone.extract(torch.from_numpy(p).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(host, dev.cpu().numpy())
+
+
+def test_extractor_contract_and_image_path(checkpoint_path, oracle_net, golden_backbone):
+    """The reference's two call shapes: patches_to_features(list[PIL]) and extractor(image, rowcols)."""
+    from PIL import Image
+    from mermaid_classifier_amd import build_extractor_class, verify_device_numerics
+    from mermaid_classifier_amd.spacer_shim import DataLocation
+    from oracle import efficientnet_b0_ref as ref
+    cls = build_extractor_class()
+    ex = cls(data_locations={"weights": DataLocation("filesystem", str(checkpoint_path))}, device="cuda", batch_size=10)
+    patches = [Image.fromarray(a) for a in ref.natural_patches(3, seed=7)]
+    feats, loaded_remote = ex.patches_to_features(patches)
+    assert loaded_remote is False and isinstance(feats, list) and isinstance(feats[0][0], float)
+    assert np.asarray(feats).shape == (3, 1280)
+    assert rel_l2(np.asarray(feats), golden_backbone["natural8"][:3]).max() < TOL_NATURAL
+    # image + rowcols (config 1 geometry scaled down; includes corner points that exercise reflect padding)
+    rng = np.random.default_rng(42)
+    image = rng.integers(0, 255, (696, 928, 3), dtype=np.uint8)
+    rowcols = [tuple(int(v) for v in rc) for rc in golden_backbone["image_rowcols"]]
+    features, msg = ex(Image.fromarray(image), rowcols)
+    got = np.vstack([features.get_array(rc) for rc in rowcols])
+    want = golden_backbone["image_features"]
+    assert features.npoints == len(rowcols) and features.feature_dim == 1280 and msg.runtime > 0
+    assert cosine(got, want).min() >= COS_GATE and rel_l2(got, want).max() < TOL_NOISE
+    # the reference's own gate, with the oracle as the CPU side
+    mn, med, mx = verify_device_numerics(ex, lambda ps: ref.patches_to_features(oracle_net, np.stack(ps)))
+    assert mn >= COS_GATE
+    with pytest.raises(ValueError):
+        ex(Image.fromarray(image), [(700, 5)])
+
+
+def test_crop_kernel_matches_oracle_bitwise():
+    from mermaid_classifier_amd.backbone import crop_patches_device
+    from oracle import pyspacer_ref
+    rng = np.random.default_rng(5)
+    image = rng.integers(0, 256, (300, 411, 3), dtype=np.uint8)
+    rowcols = [(0, 0), (299, 410), (0, 410), (299, 0), (150, 200), (1, 409), (111, 112), (113, 300)]
+    got = crop_patches_device(image, rowcols).cpu().numpy()
+    want = pyspacer_ref.crop_patches(image, rowcols, 224)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["head_fixture", "head108"])
+def test_head_matches_reference_predictor(name):
+    """HIP head vs outputs of the reference's own CalibratedHead/Predictor (golden, generated by
+    importing the reference): max|dp| <= 1e-6 (the reference's export gate, inference/export.py:31)
+    and identical argmax on every row."""
+    from mermaid_classifier_amd import load_predictor
+    io = np.load(GOLDEN / f"{name}_io.npz")
+    pred = load_predictor(GOLDEN / name / "model.pt", GOLDEN / name / "model.json")
+    got = pred.predict_proba(io["X"])
+    want = io["proba_predictor_f64"]
+    assert got.dtype == np.float64 and got.shape == want.shape
+    d = np.abs(got - want).max()
+    print(name, "max|dp|", d)
+    assert d <= 1e-6
+    assert np.array_equal(got.argmax(1), want.argmax(1))
+    assert np.abs(got.sum(1) - 1).max() < 1e-5
+    labels = pred.predict(io["X"])
+    assert labels == [pred.classes[i] for i in want.argmax(1)]
+    with pytest.raises(ValueError):
+        pred.predict_proba(np.zeros((2, pred.input_dim + 1), np.float32))
+    assert pred.predict_proba(np.zeros((0, pred.input_dim), np.float32)).shape == (0, len(pred.classes))
+
+
+def test_extract_then_classify_labels_match_oracle_chain(backbone, oracle_net):
+    """Config 3 in miniature: HIP features -> HIP head labels == oracle features -> reference-restated head labels."""
+    from mermaid_classifier_amd import load_predictor
+    from oracle import efficientnet_b0_ref as ref, head_ref
+    from mermaid_classifier_amd.inference import params_from_torchscript
+    import torch
+    pred = load_predictor(GOLDEN / "head108" / "model.pt", GOLDEN / "head108" / "model.json")
+    p = ref.natural_patches(12, seed=21)
+    f_hip = backbone.extract(p)
+    f_ref = ref.patches_to_features(oracle_net, p)
+    prm = params_from_torchscript(torch.jit.load(str(GOLDEN / "head108" / "model.pt")))
+    want = head_ref.predict_proba(f_ref, prm.weights, prm.biases, prm.a, prm.b, 1280)
+    got = pred.predict_proba(f_hip)
+    top2 = np.sort(want, 1)[:, -2:]
+    decided = (top2[:, 1] - top2[:, 0]) > 1e-3     # rows whose oracle margin exceeds the feature tolerance
+    assert np.array_equal(got.argmax(1)[decided], want.argmax(1)[decided])
+    # same features in -> identical labels, always
+    assert np.array_equal(pred.predict_proba(f_ref).argmax(1), want.argmax(1))

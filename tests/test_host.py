@@ -1,0 +1,195 @@
+"""CPU tests of the host logic: BN/normalisation folding, blob layout, checkpoint validation,
+the C-ABI surface (symbols only -- no compute without a GPU), shims and loader validation."""
+
+import ctypes
+import json
+import re
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, ROOT, rel_l2
+
+
+def _folded_forward(tensors, patches_u8):
+    """Evaluate the network from the FOLDED tensors (what the library consumes) in fp32 torch:
+    proves fold() + the stem's u8-128 / padval trick reproduce the oracle's arithmetic."""
+    from mermaid_classifier_amd.weights import B0_BLOCKS
+    t = {k: torch.from_numpy(v) for k, v in tensors}
+    u = torch.from_numpy(patches_u8.astype(np.float32) - 128.0).permute(0, 3, 1, 2)   # (B,3,224,224)
+    pv = t["stem.padval"].view(1, 3, 1, 1)
+    up = pv.expand(u.shape[0], 3, 225, 225).clone()
+    up[:, :, :224, :224] = u                                                          # pad right/bottom with padval
+    w = t["stem.weight"].view(32, 3, 3, 3).permute(0, 3, 1, 2)                        # (n,ky,kx,c)->(n,c,ky,kx)
+    x = F.conv2d(up, w, t["stem.bias"], stride=2)
+    x = x * torch.sigmoid(x)
+    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+        inp = x
+        ce = cin * e
+        if e != 1:
+            x = F.conv2d(x, t[f"b{i}.expand.weight"].view(ce, cin, 1, 1), t[f"b{i}.expand.bias"])
+            x = x * torch.sigmoid(x)
+        h = x.shape[2]
+        out = -(-h // s)
+        pad = max((out - 1) * s + k - h, 0)
+        x = F.pad(x, (pad // 2, pad - pad // 2, pad // 2, pad - pad // 2))
+        x = F.conv2d(x, t[f"b{i}.dw.weight"].view(ce, 1, k, k), t[f"b{i}.dw.bias"], stride=s, groups=ce)
+        x = x * torch.sigmoid(x)
+        pooled = x.mean(dim=(2, 3))
+        r = pooled @ t[f"b{i}.se.reduce.weight"].T + t[f"b{i}.se.reduce.bias"]
+        r = r * torch.sigmoid(r)
+        g = torch.sigmoid(r @ t[f"b{i}.se.expand.weight"].T + t[f"b{i}.se.expand.bias"])
+        x = x * g[:, :, None, None]
+        x = F.conv2d(x, t[f"b{i}.project.weight"].view(cout, ce, 1, 1), t[f"b{i}.project.bias"])
+        if s == 1 and cin == cout:
+            x = x + inp
+    x = F.conv2d(x, t["head.weight"].view(1280, 320, 1, 1), t["head.bias"])
+    x = x * torch.sigmoid(x)
+    return x.mean(dim=(2, 3)).numpy()
+
+
+def test_fold_reproduces_oracle(synth_sd, oracle_net):
+    from mermaid_classifier_amd import weights
+    from oracle import efficientnet_b0_ref as ref
+    sd = {k: np.asarray(v.numpy(), np.float64) for k, v in synth_sd.items() if k in weights.expected_shapes()}
+    tensors = weights.fold(sd)
+    patches = np.concatenate([ref.synthetic_patches(1, seed=42), ref.natural_patches(1, seed=7)])
+    with torch.no_grad():
+        got = _folded_forward(tensors, patches)
+        want = oracle_net.extract_features(ref.transformation(patches)).numpy()
+    assert rel_l2(got, want).max() < 2e-5
+
+
+def test_blob_layout_roundtrip(synth_sd):
+    from mermaid_classifier_amd import weights
+    sd = {k: np.asarray(v.numpy(), np.float64) for k, v in synth_sd.items() if k in weights.expected_shapes()}
+    blob = weights.pack_backbone(sd)
+    assert blob[:4] == b"MMCW"
+    version, arch, n = struct.unpack_from("<III", blob, 4)
+    tensors = weights.fold(sd)
+    assert (version, arch, n) == (1, 0, len(tensors)) and n == 3 + 16 * 10 - 2 + 2
+    for i, (_, a) in enumerate(tensors):
+        off, nb = struct.unpack_from("<QQ", blob, 16 + 16 * i)
+        assert off % 256 == 0 and nb == a.nbytes
+        assert np.array_equal(np.frombuffer(blob, np.float32, a.size, off).reshape(a.shape), a)
+
+
+def test_checkpoint_validation_is_loud(synth_sd, checkpoint_path, tmp_path):
+    from mermaid_classifier_amd import weights
+    sd = weights.load_checkpoint(str(checkpoint_path))     # pyspacer layout: {'net': {'module.x': ...}}
+    assert set(sd) == set(weights.expected_shapes())
+    broken = {("module." + k): v for k, v in synth_sd.items() if "_blocks.3._se_reduce" not in k}
+    broken["module._blocks.99.bogus"] = torch.zeros(1)
+    p = tmp_path / "broken.pt"
+    torch.save({"net": broken}, p)
+    with pytest.raises(weights.WeightsError) as ei:
+        weights.load_checkpoint(str(p))
+    assert "_blocks.3._se_reduce.weight" in str(ei.value) and "_blocks.99.bogus" in str(ei.value)
+    torch.save({"something": 1}, p)
+    with pytest.raises(weights.WeightsError):
+        weights.load_checkpoint(str(p))
+
+
+def test_abi_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly the entry points include/mmc.h declares."""
+    from mermaid_classifier_amd import _lib
+    header = (ROOT / "include" / "mmc.h").read_text()
+    declared = sorted(set(re.findall(r"\b(mmc_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(_lib.SYMBOLS)
+    lib = _lib.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.mmc_version() == 1
+    assert lib.mmc_device_count() >= 0
+
+
+def test_no_cpu_fallback_without_device(checkpoint_path):
+    """Without a HIP device the product path refuses loudly instead of computing on the CPU."""
+    from mermaid_classifier_amd import _lib
+    if _lib.lib().mmc_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from mermaid_classifier_amd.backbone import Backbone
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        Backbone(str(checkpoint_path), device=0, max_batch=4)
+    from mermaid_classifier_amd import load_predictor
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        load_predictor(GOLDEN / "head_fixture" / "model.pt", GOLDEN / "head_fixture" / "model.json")
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    from mermaid_classifier_amd import _lib
+    monkeypatch.setenv("MMC_LIBRARY", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.LibraryMissingError):
+        _lib._load()
+
+
+def test_product_package_never_imports_the_oracle():
+    src = ROOT / "mermaid_classifier_amd"
+    for f in src.rglob("*.py"):
+        txt = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+    for f in (src / "csrc").iterdir():
+        assert "oracle" not in f.read_text(errors="ignore").lower().replace("oracle/efficientnet_b0_ref.py", ""), f
+
+
+def test_params_from_torchscript_match_reference_parameters():
+    from mermaid_classifier_amd.inference import params_from_torchscript
+    io = np.load(GOLDEN / "head_fixture_io.npz")
+    prm = params_from_torchscript(torch.jit.load(str(GOLDEN / "head_fixture" / "model.pt")))
+    assert prm.dims == [8, 16, 5]
+    for i in range(int(io["n_layers"])):
+        assert np.array_equal(prm.weights[i], io[f"W{i}"]) and np.array_equal(prm.biases[i], io[f"b{i}"])
+    assert np.array_equal(prm.a, io["a"]) and np.array_equal(prm.b, io["b"])
+    big = params_from_torchscript(torch.jit.load(str(GOLDEN / "head108" / "model.pt")))
+    assert big.dims == [1280, 500, 300, 100, 108]
+
+
+def test_loader_manifest_errors_before_touching_the_gpu(tmp_path):
+    """Mirrors reference tests/pyspacer/test_portable_artifact.py:122-147."""
+    from mermaid_classifier_amd import ManifestError, load_predictor
+    pt = GOLDEN / "head_fixture" / "model.pt"
+    manifest = json.loads((GOLDEN / "head_fixture" / "model.json").read_text())
+    for mutate, pattern in (
+        (lambda m: m.update(schema_version=2), "schema_version"),
+        (lambda m: m.update(classes=m["classes"][:-1]), "class-count"),
+        (lambda m: m.update(input_dim=9), "input_dim"),
+    ):
+        m = json.loads(json.dumps(manifest))
+        mutate(m)
+        j = tmp_path / "model.json"
+        j.write_text(json.dumps(m))
+        with pytest.raises(ManifestError, match=pattern):
+            load_predictor(pt, j)
+
+
+def test_shim_image_features_roundtrip(tmp_path):
+    from mermaid_classifier_amd.spacer_shim import DataLocation, ImageFeatures, PointFeatures
+    pfs = [PointFeatures(3, 4, [0.5, 1.5]), PointFeatures(7, 1, [2.0, -1.0])]
+    feats = ImageFeatures(pfs, True, 2, 2)
+    assert np.array_equal(feats.get_array((7, 1)), [2.0, -1.0])
+    loc = DataLocation("filesystem", str(tmp_path / "i1.featurevector"))
+    feats.store(loc)
+    back = ImageFeatures.load(loc)
+    assert back.serialize() == feats.serialize()
+    with pytest.raises(ValueError):
+        DataLocation("s3", "k")
+
+
+def test_extractor_constructor_shapes(checkpoint_path):
+    """Both reference call shapes construct without touching the GPU (net is built lazily)."""
+    from mermaid_classifier_amd import EfficientNetExtractor, build_extractor_class
+    from mermaid_classifier_amd.spacer_shim import DataLocation
+    loc = DataLocation("filesystem", str(checkpoint_path))
+    a = build_extractor_class()(data_locations={"weights": loc}, device="cuda", batch_size=10)
+    b = EfficientNetExtractor(data_locations={"weights": loc})
+    assert a.feature_dim == b.feature_dim == 1280 and a.CROP_SIZE == 224 and a.DATA_LOCATION_KEYS == ["weights"]
+    ds, remote = a.load_datastream("weights")
+    assert remote is False and len(ds.read()) > 1_000_000
+    with pytest.raises(ValueError):
+        build_extractor_class()(data_locations={}, device="cuda", batch_size=10)
+    with pytest.raises(ValueError):
+        build_extractor_class()(data_locations={"weights": loc}, device="cuda", batch_size=0)
