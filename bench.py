@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- patches/s of the EfficientNet-B0 feature-extraction hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of 256 synthetic 224x224 u8 patches per
+GPU (BASELINE.json configs[1]: "EfficientNet-B0 forward, batch=256 random 224x224 patches"),
+resident in HBM before the timed region; for N > 1 ranks hold independent shards (weak scaling)
+and the step ends with the RCCL all-gather of the (N*256, 1280) feature matrix (configs[3]).
+Rank 0 prints ONE JSON line.  The oracle is imported only for the cpu_baseline leg.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+BATCH = 256
+
+
+def synth_weights():
+    """Synthetic seeded backbone weights (no checkpoint exists offline): the same generator the
+    tests use, with the committed calibrated BN statistics."""
+    from mermaid_classifier_amd.synthetic import synthetic_state_dict
+    stats = dict(np.load(ROOT / "tests" / "golden" / "synth_bn_stats.npz"))
+    return synthetic_state_dict(seed=0, bn_stats=stats)
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota), not os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                    n = min(n, max(1, q // period))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(sd, budget_s: float = 15.0):
+    """The reference's CPU path restated (oracle): config-1 geometry, one 4872x5568 image x 10
+    points, crop (reflect pad) + transform + B0 forward (batch 10) + tolist, fp32, all host cores."""
+    import torch
+    from oracle import efficientnet_b0_ref as ref, pyspacer_ref
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    net = ref.EfficientNetB0Ref({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    rng = np.random.default_rng(42)
+    image = rng.integers(0, 255, (4872, 5568, 3), dtype=np.uint8)
+    rows, cols = [812, 1624], [928, 1856, 2784, 3712, 4640]
+    rowcols = [(r, c) for r in rows for c in cols][:10]
+    pyspacer_ref.extract(net, image, rowcols, batch_size=10)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        feats = pyspacer_ref.extract(net, image, rowcols, batch_size=10)
+        feats.tolist()
+        n += len(rowcols)
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 2000:
+            break
+    return {"value": n / dt, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": f"{n // 10} x (1 image 4872x5568 x 10 points: crop+transform+B0 fp32 batch 10+tolist), torch CPU {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-passes", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mermaid_classifier_amd.backbone import Backbone
+    from mermaid_classifier_amd import schedule
+
+    sd = synth_weights()
+    bb = Backbone(sd, device=local_rank, max_batch=BATCH)
+    rng = np.random.default_rng(42 + rank)
+    patches = torch.from_numpy(rng.integers(0, 255, (BATCH, 224, 224, 3), dtype=np.uint8)).to(dev)
+    feats = torch.empty((BATCH, 1280), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * BATCH, 1280), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        bb.extract(patches, out=feats)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, feats)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not np.isfinite(feats.float().sum().item()):
+        raise SystemExit("non-finite features")
+
+    if rank == 0:
+        value = world * BATCH * args.steps / elapsed
+        # per-kernel durations, HIP events on the launch stream, same resident workload
+        per_kernel = defaultdict(lambda: [0.0, 0, 0])  # ms, launches, bytes
+        alg = {l.name: l for l in schedule.b0_launches(BATCH)}
+        launched = []
+        for _ in range(args.profile_passes):
+            for name, ms in bb.profile(patches, feats):
+                layer, kern = name.split("|")
+                launched.append(layer)
+                e = per_kernel[kern]
+                e[0] += ms
+                e[1] += 1
+                e[2] += alg[layer].bytes
+        dom, (ms, launches, nbytes) = max(per_kernel.items(), key=lambda kv: kv[1][0])
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        tot = schedule.totals(BATCH, launched)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": schedule.HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / schedule.HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
+                    "alg_bytes_per_launch": nbytes / launches,
+                    "whole_net": {"alg_GB_per_step": tot["bytes"] / 1e9,
+                                  "hbm_frac_at_value": tot["bytes_per_patch"] * value / 1e9 / schedule.HBM_PEAK_GBS,
+                                  "mfma_frac_at_value": tot["flops_per_patch"] * value / 1e12 / schedule.MFMA_F16_PEAK_TFLOPS}}
+        out = {
+            "metric": "patches/sec (224x224 EfficientNet-B0)", "value": value, "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "EfficientNet-B0 forward, batch=256 random 224x224 u8 patches per GPU -> (256,1280) fp32"
+                                   + ("; RCCL all-gather of features" if world > 1 else ""),
+                       "per_gpu_batch": BATCH, "global_batch": world * BATCH, "weights": "synthetic seed 0",
+                       "parallelism": f"patch-sharded x{world}"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        kernels = sorted(((k, v[0] / args.profile_passes) for k, v in per_kernel.items()), key=lambda kv: -kv[1])
+        print("# per-kernel ms/step (HIP events): " + ", ".join(f"{k}={v:.3f}" for k, v in kernels), file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

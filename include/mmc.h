@@ -82,10 +82,10 @@ int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, float* out,
                                  size_t* n_written);
 
 /* Kernel timing hook for bench.py: runs `iters` passes over `n` resident patches and returns the
- * HIP-event elapsed milliseconds of each named kernel class, measured on `hip_stream`.
+ * HIP-event elapsed milliseconds of every launch ("<layer>|<kernel instantiation>"), measured on `hip_stream`.
  * names/ms arrays have `cap` slots; *n_out receives the number filled. */
 int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, float* out_features_dev,
-                         void* hip_stream, char (*names)[48], float* ms, int* launches, int cap, int* n_out);
+                         void* hip_stream, char (*names)[64], float* ms, int* launches, int cap, int* n_out);
 
 /* ---- GPU crop front-end ---------------------------------------------------------------
  * Replaces: pyspacer crop_patches(image, rowcols, 224) as called by FeatureExtractor.__call__

@@ -126,7 +126,7 @@ class Backbone:
     def profile(self, patches_dev, out_dev) -> List[Tuple[str, float]]:
         """One pass with HIP events around every launch -> [(launch name, ms)]."""
         cap = 128
-        names = ((C.c_char * 48) * cap)()
+        names = ((C.c_char * 64) * cap)()
         ms = (C.c_float * cap)()
         launches = (C.c_int * cap)()
         n_out = C.c_int(0)

@@ -33,6 +33,21 @@ struct DwArgs {
     int CG, S, iters, parts;
 };
 
+struct MbArgs {
+    const _Float16* X;      // [B][H][W][Cin]
+    const _Float16* Wexp;   // [Ce][32*ksteps] natural rows, zero-padded K
+    const float* bexp;
+    const float* Wdw;       // [ks*ks][Ce]
+    const float* bdw;
+    _Float16* out;          // [B][Ho][Wo][Ce]
+    float* pool_part;       // [B][tiles][Ce]
+    int B, H, W, Cin, Ce, Ho, Wo, pad;
+    int ks, stride, tw, ksteps;
+    int TH, TWo, tiles_x, tiles_y, CC, CCG, S;
+    int red_off, lds_bytes;
+};
+
+int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
                 hipStream_t st);
 int launch_pw_gemm(const GemmArgs& a, hipStream_t st);

@@ -22,8 +22,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-static __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-static __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division: results are rounded to fp16 anyway.
+static __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+static __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // ---------------------------------------------------------------------------------------------
 // Stem: u8 HWC patch -> conv3x3 stride 2 (TF-same: pad right/bottom by 1) -> +bias -> SiLU -> fp16
@@ -355,11 +356,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
 // Squeeze-excite gate: one workgroup per patch.
 //   pooled[c] = inv_hw * sum_p pool_part[b][p][c]
 //   r[j]      = silu(b_r[j] + sum_c W_r[j][c] pooled[c])        j < Cs   (wave-reduced dot products)
-//   gate[c]   = sigmoid(b_e[c] + sum_j W_e[c][j] r[j])
+//   gate[c]   = sigmoid(b_e[c] + sum_j W_e[c][j] r[j])      (W_e stored transposed, [Cs][C])
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
                                                       float inv_hw, const float* __restrict__ Wr,
-                                                      const float* __restrict__ br, const float* __restrict__ We,
+                                                      const float* __restrict__ br, const float* __restrict__ WeT,
                                                       const float* __restrict__ be, float* __restrict__ gate)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C] + r[Cs]
@@ -373,18 +374,26 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
         pooled[c] = s * inv_hw;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j = wave; j < Cs; j += 4) {
+    // reduce FC: 16 groups of 16 lanes, one output j per group per round, 16-byte loads along C
+    const int g = tid >> 4, l = tid & 15;
+    for (int j = g; j < Cs; j += 16) {
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += Wr[(size_t)j * C + c] * pooled[c];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) r[j] = silu_f(s + br[j]);
+        for (int c = l * 4; c < C; c += 64) {
+            const f4 w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + c);
+            const f4 x = *reinterpret_cast<const f4*>(pooled + c);
+            s += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 1);
+        if (l == 0) r[j] = silu_f(s + br[j]);
     }
     __syncthreads();
+    // expand FC: WeT is [Cs][C] so neighbouring lanes read neighbouring floats
     for (int c = tid; c < C; c += 256) {
         float s = be[c];
-        for (int j = 0; j < Cs; ++j) s += We[(size_t)c * Cs + j] * r[j];
+        for (int j = 0; j < Cs; ++j) s += WeT[(size_t)j * C + c] * r[j];
         gate[(size_t)b * C + c] = sigmoid_f(s);
     }
 }
@@ -406,9 +415,14 @@ __global__ __launch_bounds__(256) void mlp_gemm_f32_kernel(const float* __restri
     const int row = (blockIdx.x * 4 + wave) * 16 + i;
     const bool rok = row < M;
     const int n0 = blockIdx.y * 16 * NT;
-    f4 acc[NT];
+    // four independent accumulation chains per fragment (k-step s feeds chain s): shorter chains
+    // than one 1280-long fma sequence -> less fp32 drift against the reference's blocked sgemm,
+    // and no MFMA dependent-issue stalls.
+    f4 acc[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[t][s] = (f4){0.f, 0.f, 0.f, 0.f};
     const int K16 = K & ~15;
     for (int k0 = 0; k0 < K16; k0 += 16) {
         f4 xv = {0.f, 0.f, 0.f, 0.f};
@@ -419,10 +433,11 @@ __global__ __launch_bounds__(256) void mlp_gemm_f32_kernel(const float* __restri
             f4 wv = {0.f, 0.f, 0.f, 0.f};
             if (n < N) wv = *reinterpret_cast<const f4*>(W + (size_t)n * K + k0 + 4 * q);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t], 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+                acc[t][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t][s], 0, 0, 0);
         }
     }
-    if (K16 < K) {  // K tail (K % 16 != 0): scalar-guarded loads, K is a multiple of 4 for every head layer
+    if (K16 < K) {  // K tail: K is padded to a multiple of 4 by mmc_head_create
         f4 xv = {0.f, 0.f, 0.f, 0.f};
         const int k = K16 + 4 * q;
         if (rok && k < K) xv = *reinterpret_cast<const f4*>(X + (size_t)row * K + k);
@@ -432,7 +447,8 @@ __global__ __launch_bounds__(256) void mlp_gemm_f32_kernel(const float* __restri
             f4 wv = {0.f, 0.f, 0.f, 0.f};
             if (n < N && k < K) wv = *reinterpret_cast<const f4*>(W + (size_t)n * K + k);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t], 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+                acc[t][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[t][s], 0, 0, 0);
         }
     }
     // swapped operands: lane (i,q) holds outputs n = n0 + 16t + 4q + j of row `row`
@@ -443,7 +459,7 @@ __global__ __launch_bounds__(256) void mlp_gemm_f32_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + t * 16 + 4 * q + j;
             if (n < N) {
-                float v = acc[t][j] + bias[n];
+                float v = ((acc[t][0][j] + acc[t][1][j]) + (acc[t][2][j] + acc[t][3][j])) + bias[n];
                 if (RELU) v = fmaxf(v, 0.f);
                 Y[(size_t)row * N + n] = v;
             }
@@ -525,6 +541,172 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ i
     dst[0] = w[0];
     dst[1] = w[1];
     dst[2] = w[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused MBConv front half: expand 1x1 (+bias+SiLU) -> LDS -> depthwise KSxKS stride ST (+bias+SiLU)
+// -> fp16 NHWC to HBM, plus squeeze-excite partial sums.  The 6x-expanded tensor never leaves the CU.
+// One workgroup = (patch, output tile TH x TWo, chunk of CC expanded channels).
+//   phase 1: the tile's input window (halo included, clipped to the image) is P positions x Cin;
+//            each wave runs two 16-position MFMA fragments at a time against the chunk's weights
+//            (weights = A operand, positions = B operand) and writes silu(acc+bias) as fp16 into
+//            LDS E[position][CC] (row stride CC*2+16 bytes: 16-B aligned rows, spread over banks).
+//   phase 2: the depthwise conv reads E with 16-byte LDS reads (8 channels x TW output pixels per
+//            thread, fp32 accumulate); image borders are handled by tap predication (the padding is
+//            zero in the expanded domain, so skipped taps are exact).
+// ---------------------------------------------------------------------------------------------
+template <int KS, int ST, int TW, int KSTEPS>
+__global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
+                                                       const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
+                                                       const float* __restrict__ bexp,     // [Ce]
+                                                       const float* __restrict__ Wdw,      // [KS*KS][Ce]
+                                                       const float* __restrict__ bdw,      // [Ce]
+                                                       _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
+                                                       float* __restrict__ pool_part,      // [B][ntiles][Ce]
+                                                       int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
+                                                       int TWo, int tiles_x, int CC, int CCG, int S, int red_off)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int Kp = 32 * KSTEPS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TWo;
+    // input window of this tile, clipped to the image
+    int wy0 = oy0 * ST - pad, wy1 = (oy0 + TH - 1) * ST - pad + KS;
+    int wx0 = ox0 * ST - pad, wx1 = (ox0 + TWo - 1) * ST - pad + KS;
+    wy0 = wy0 < 0 ? 0 : wy0;
+    wx0 = wx0 < 0 ? 0 : wx0;
+    wy1 = wy1 > H ? H : wy1;
+    wx1 = wx1 > W ? W : wx1;
+    const int ww = wx1 - wx0;
+    const int P = (wy1 - wy0) * ww;
+    const int ES = CC * 2 + 16;  // bytes per E row
+    const int NTC = CC >> 4;
+    // ---------------- phase 1: expand GEMM into LDS ----------------
+    {
+        const int MTn = (P + 15) >> 4;
+        const _Float16* wbase = Wexp + ((size_t)chunk * CC + m) * Kp + q * 8;
+        const float* bb = bexp + chunk * CC + 4 * q;
+        for (int mt = wave * 2; mt < MTn; mt += 8) {
+            int p[2];
+            bool pok[2];
+            h8 xf[2][KSTEPS];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                p[i] = (mt + i) * 16 + m;
+                pok[i] = p[i] < P;
+                const int py = p[i] / ww, px = p[i] - py * ww;
+                const _Float16* xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (pok[i] && ks * 32 + q * 8 < Cin) v = *reinterpret_cast<const h8*>(xp + ks * 32);
+                    xf[i][ks] = v;
+                }
+            }
+            for (int t = 0; t < NTC; ++t) {
+                f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const h8 wf = *reinterpret_cast<const h8*>(wbase + (size_t)t * 16 * Kp + ks * 32);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[1][ks], a1, 0, 0, 0);
+                }
+                const f4 bv = *reinterpret_cast<const f4*>(bb + t * 16);
+                h4 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o0[j] = (_Float16)silu_f(a0[j] + bv[j]);
+                    o1[j] = (_Float16)silu_f(a1[j] + bv[j]);
+                }
+                if (pok[0]) *reinterpret_cast<h4*>(smem + (size_t)p[0] * ES + (t * 16 + 4 * q) * 2) = o0;
+                if (pok[1]) *reinterpret_cast<h4*>(smem + (size_t)p[1] * ES + (t * 16 + 4 * q) * 2) = o1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2: depthwise from LDS ----------------
+    float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]
+    const bool active = tid < CCG * S;
+    const int cg = tid % CCG, s = tid / CCG;
+    const int cglob = chunk * CC + cg * 8;
+    const int spr = TWo / TW;
+    const int nstrips = TH * spr;
+    float pooled[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pooled[j] = 0.f;
+    if (active) {
+        float bs[8];
+        {
+            const f4 b0 = *reinterpret_cast<const f4*>(bdw + cglob);
+            const f4 b1 = *reinterpret_cast<const f4*>(bdw + cglob + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
+        }
+        constexpr int NX = (TW - 1) * ST + KS;
+        _Float16* outb = out + (size_t)b * Ho * Wo * Ce + cglob;
+        for (int strip = s; strip < nstrips; strip += S) {
+            const int oyl = strip / spr;
+            const int oy = oy0 + oyl, ox = ox0 + (strip - oyl * spr) * TW;
+            float acc[TW][8];
+#pragma unroll
+            for (int t = 0; t < TW; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+#pragma unroll 1
+            for (int ky = 0; ky < KS; ++ky) {
+                const int iy = oy * ST - pad + ky;
+                if (iy < 0 || iy >= H) continue;
+                const int rbase = (iy - wy0) * ww - wx0;  // E row of (iy, ix) is rbase + ix
+                float wk[KS][8];
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const f4 w0 = *reinterpret_cast<const f4*>(Wdw + (size_t)(ky * KS + kx) * Ce + cglob);
+                    const f4 w1 = *reinterpret_cast<const f4*>(Wdw + (size_t)(ky * KS + kx) * Ce + cglob + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
+                }
+#pragma unroll
+                for (int xr = 0; xr < NX; ++xr) {
+                    const int ix = ox * ST - pad + xr;
+                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ix >= 0 && ix < W) v = *reinterpret_cast<const h8*>(smem + (rbase + ix) * ES + cg * 16);
+                    float vf[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vf[j] = (float)v[j];
+#pragma unroll
+                    for (int t = 0; t < TW; ++t) {
+                        const int kx = xr - t * ST;
+                        if (kx >= 0 && kx < KS) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[t][j] = __builtin_fmaf(vf[j], wk[kx][j], acc[t][j]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+                h8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = silu_f(acc[t][j] + bs[j]);
+                    pooled[j] += y;
+                    o[j] = (_Float16)y;
+                }
+                *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox + t) * Ce) = o;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[s * CC + cg * 8 + j] = pooled[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < CC; c += 256) {
+        float sum = 0.f;
+        for (int ss = 0; ss < S; ++ss) sum += red[ss * CC + c];
+        pool_part[((size_t)b * gridDim.x + tile) * Ce + chunk * CC + c] = sum;
+    }
 }
 
 // =============================================================================================
@@ -673,4 +855,34 @@ int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int 
     hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, st, image, H, W, rowcols, out);
     LAUNCH_CHECK();
     return 0;
+}
+
+template <int KS, int ST, int TW, int KSTEPS>
+static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
+{
+    dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, a.B);
+    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp, a.bexp,
+                       a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH, a.TWo,
+                       a.tiles_x, a.CC, a.CCG, a.S, a.red_off);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mbconv_a(const MbArgs& a, hipStream_t st)
+{
+#define MB_CASE(KS, ST, TW, KSTEPS) \
+    if (a.ks == KS && a.stride == ST && a.tw == TW && a.ksteps == KSTEPS) return launch_mbconv_t<KS, ST, TW, KSTEPS>(a, st);
+    MB_CASE(3, 2, 4, 1)
+    MB_CASE(3, 1, 7, 1)
+    MB_CASE(5, 2, 7, 1)
+    MB_CASE(5, 1, 7, 2)
+    MB_CASE(3, 2, 7, 2)
+    MB_CASE(3, 1, 7, 3)
+    MB_CASE(5, 1, 7, 3)
+    MB_CASE(5, 1, 7, 4)
+    MB_CASE(5, 2, 7, 4)
+    MB_CASE(5, 1, 7, 6)
+    MB_CASE(3, 1, 7, 6)
+#undef MB_CASE
+    return -5;
 }

@@ -90,7 +90,20 @@ struct BlockW {
     float *se_wr = nullptr, *se_br = nullptr, *se_we = nullptr, *se_be = nullptr;
     // depthwise launch geometry
     int tw = 0, CG = 0, S = 0, iters = 0, parts = 0;
+    // fused expand+depthwise (mbconv_a_kernel) geometry; fused == false -> separate GEMM + dwconv
+    bool fused = false;
+    _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
+    int f_TH = 0, f_TWo = 0, f_CC = 0, f_tw = 0, f_ksteps = 0, f_CCG = 0, f_S = 0, f_tiles_x = 0, f_tiles_y = 0,
+        f_red_off = 0, f_lds = 0;
 };
+
+// Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
+// chosen so that E[P][CC] + the pool scratch stay <= 64 KB of LDS (>= 2 workgroups per CU) while
+// the halo recompute and the per-chunk re-read of the (small) block input stay low.
+struct FuseCfg { int TH, TWo, CC; };
+static const FuseCfg B0_FUSE[16] = {
+    {0, 0, 0},     {8, 8, 48},    {8, 14, 48},   {7, 7, 48},   {14, 14, 48},  {7, 7, 48},    {14, 14, 96},  {14, 14, 96},
+    {14, 14, 96},  {14, 14, 96},  {14, 14, 96},  {7, 7, 96},   {7, 7, 192},   {7, 7, 192},   {7, 7, 192},   {7, 7, 192}};
 
 struct Saved {
     void* dev = nullptr;
@@ -260,6 +273,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TRY_OR_FREE(dev_upload(bb, &bb->stem_pad, pvv));
     }
     // ---- blocks ----
+    const char* fuse_env = getenv("MMC_FUSE");
+    const bool fuse_enabled = !(fuse_env && fuse_env[0] == '0');
     int H = IMG / 2;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
     int max_c = 0;
@@ -273,11 +288,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         B.skip = B.d.s == 1 && B.d.cin == B.d.cout;
         same_pad(H, B.d.k, B.d.s, &B.pad, &B.Ho);
         char nm[64];
+        const float* exp_w_host = nullptr;
         if (B.has_expand) {
             snprintf(nm, sizeof nm, "b%d.expand", i);
             TAKE(w, (size_t)B.ce * B.d.cin, nm);
             TAKE(b, B.ce, nm);
             TRY_OR_FREE(pack_pw(bb, &B.expand, w, b, B.ce, B.d.cin, 0));
+            exp_w_host = w;
         }
         {
             snprintf(nm, sizeof nm, "b%d.dw", i);
@@ -298,7 +315,10 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(be, B.ce, nm);
             TRY_OR_FREE(dev_upload(bb, &B.se_wr, std::vector<float>(wr, wr + (size_t)B.cs * B.ce)));
             TRY_OR_FREE(dev_upload(bb, &B.se_br, std::vector<float>(br, br + B.cs)));
-            TRY_OR_FREE(dev_upload(bb, &B.se_we, std::vector<float>(we, we + (size_t)B.ce * B.cs)));
+            std::vector<float> weT((size_t)B.cs * B.ce);   // [Cs][Ce]: coalesced reads in se_gate_kernel
+            for (int c = 0; c < B.ce; ++c)
+                for (int j = 0; j < B.cs; ++j) weT[(size_t)j * B.ce + c] = we[(size_t)c * B.cs + j];
+            TRY_OR_FREE(dev_upload(bb, &B.se_we, weT));
             TRY_OR_FREE(dev_upload(bb, &B.se_be, std::vector<float>(be, be + B.ce)));
         }
         {
@@ -315,7 +335,41 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         const int passes = (strips + B.S - 1) / B.S;
         B.iters = passes >= 8 ? 4 : 1;
         B.parts = (passes + B.iters - 1) / B.iters;
-        if ((size_t)H * H * B.ce > max_exp && B.has_expand) max_exp = (size_t)H * H * B.ce;
+        if (B.has_expand && fuse_enabled) {
+            FuseCfg fc = B0_FUSE[i];
+            if (const char* ov = getenv("MMC_FUSE_CFG")) {   // "i:TH,TWo,CC;..." experiment override
+                char key[16];
+                snprintf(key, sizeof key, "%d:", i);
+                const char* hit = strstr(ov, key);
+                while (hit && hit != ov && hit[-1] != ';') hit = strstr(hit + 1, key);
+                if (hit) sscanf(hit + strlen(key), "%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC);
+            }
+            if (fc.TH > 0 && B.Ho % fc.TH == 0 && B.Ho % fc.TWo == 0 && B.ce % fc.CC == 0 && fc.CC % 16 == 0) {
+                B.f_TH = fc.TH; B.f_TWo = fc.TWo; B.f_CC = fc.CC;
+                B.f_tw = fc.TWo % 7 == 0 ? 7 : 4;
+                B.f_ksteps = (B.d.cin + 31) / 32;
+                B.f_CCG = fc.CC / 8;
+                B.f_S = 256 / B.f_CCG;
+                B.f_tiles_x = B.Ho / fc.TWo; B.f_tiles_y = B.Ho / fc.TH;
+                int wh = (fc.TH - 1) * B.d.s + B.d.k, wwid = (fc.TWo - 1) * B.d.s + B.d.k;
+                if (wh > H) wh = H;
+                if (wwid > H) wwid = H;
+                const int ppad = (wh * wwid + 15) / 16 * 16;
+                B.f_red_off = ppad * (fc.CC * 2 + 16);
+                B.f_lds = B.f_red_off + B.f_S * fc.CC * 4;
+                const int kp = 32 * B.f_ksteps;
+                if (B.f_lds <= 64 * 1024 && fc.TWo % B.f_tw == 0) {
+                    std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
+                    for (int c = 0; c < B.ce; ++c)
+                        for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)exp_w_host[(size_t)c * B.d.cin + k];
+                    TRY_OR_FREE(dev_upload(bb, &B.exp_nat, wn));
+                    B.fused = true;
+                    const size_t pp = (size_t)B.f_tiles_x * B.f_tiles_y * B.ce;
+                    if (pp > max_pool) max_pool = pp;
+                }
+            }
+        }
+        if ((size_t)H * H * B.ce > max_exp && B.has_expand && !B.fused) max_exp = (size_t)H * H * B.ce;
         if ((size_t)B.Ho * B.Ho * B.ce > max_dw) max_dw = (size_t)B.Ho * B.Ho * B.ce;
         if ((size_t)B.Ho * B.Ho * B.d.cout > max_act) max_act = (size_t)B.Ho * B.Ho * B.d.cout;
         if ((size_t)B.parts * B.ce > max_pool) max_pool = (size_t)B.parts * B.ce;
@@ -334,7 +388,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const size_t mb = (size_t)max_batch;
     TRY_OR_FREE(dev_alloc(bb, &bb->act0, mb * max_act));
     TRY_OR_FREE(dev_alloc(bb, &bb->act1, mb * max_act));
-    TRY_OR_FREE(dev_alloc(bb, &bb->expbuf, mb * max_exp));
+    TRY_OR_FREE(dev_alloc(bb, &bb->expbuf, mb * (max_exp ? max_exp : 64)));
     TRY_OR_FREE(dev_alloc(bb, &bb->dwbuf, mb * max_dw));
     TRY_OR_FREE(dev_alloc(bb, &bb->pool_part, mb * max_pool));
     TRY_OR_FREE(dev_alloc(bb, &bb->gate, mb * (size_t)max_c));
@@ -368,6 +422,20 @@ static int save_act(mmc_backbone* bb, const char* name, const void* dev, size_t 
     return 0;
 }
 
+static int gemm_mt(const PwLayer& L, int M)
+{
+    // two row fragments per wave when that still leaves >= ~4 workgroups per CU
+    const long wgs2 = ((long)M + 127) / 128 * L.n_chunks;
+    return wgs2 >= 1024 ? 2 : 1;
+}
+
+static std::string gemm_label(const PwLayer& L, int M, int epi, bool gate, bool res)
+{
+    char b[64];
+    snprintf(b, sizeof b, "pw_gemm<%d,%d,%d,%d,%d>", epi == EPI_GAP ? 1 : gemm_mt(L, M), L.nt, epi, gate ? 1 : 0, res ? 1 : 0);
+    return b;
+}
+
 static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int epi, const float* gate, int HW,
                     const _Float16* res, float* gap_out, hipStream_t st)
 {
@@ -375,19 +443,17 @@ static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int
     a.X = X; a.M = M; a.K = L.K; a.Wp = L.w; a.Kp = L.Kp; a.bias = L.b; a.Y = Y; a.N = L.N;
     a.nt = L.nt; a.n_chunks = L.n_chunks; a.epi = epi; a.gate = gate; a.HW = HW; a.res = res;
     a.gap_out = gap_out; a.inv_hw = 1.0f / (float)HW;
-    // two row fragments per wave when that still leaves >= ~4 workgroups per CU
-    const long wgs2 = ((long)M + 127) / 128 * L.n_chunks;
-    a.mt = wgs2 >= 1024 ? 2 : 1;
+    a.mt = gemm_mt(L, M);
     return launch_pw_gemm(a, st);
 }
 
 static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
 {
-#define STEP(nm, expr)                                                                  \
+#define STEP(nm, label, expr)                                                           \
     do {                                                                                \
         ProfEntry pe_;                                                                  \
         if (prof) {                                                                     \
-            pe_.name = (nm);                                                            \
+            pe_.name = std::string(nm) + "|" + std::string(label);                     \
             HIP_TRY(hipEventCreate(&pe_.e0));                                           \
             HIP_TRY(hipEventCreate(&pe_.e1));                                           \
             HIP_TRY(hipEventRecord(pe_.e0, st));                                        \
@@ -401,37 +467,56 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
     char nm[64];
     _Float16* x = bb->act0;
     _Float16* y = bb->act1;
-    STEP("stem", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
+    STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
     if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     for (int i = 0; i < 16; ++i) {
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
-        const _Float16* dw_in = x;
-        if (B.has_expand) {
-            snprintf(nm, sizeof nm, "b%d.expand", i);
-            STEP(nm, run_gemm(B.expand, x, n * HWi, bb->expbuf, EPI_SILU, nullptr, HWi, nullptr, nullptr, st));
-            if (bb->keep) { int r = save_act(bb, nm, bb->expbuf, (size_t)n * HWi * B.ce, true, st); if (r) return r; }
-            dw_in = bb->expbuf;
+        int nparts = B.parts;
+        if (B.fused) {
+            MbArgs a{};
+            a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = bb->dwbuf;
+            a.pool_part = bb->pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
+            a.Wo = B.Ho; a.pad = B.pad; a.ks = B.d.k; a.stride = B.d.s; a.tw = B.f_tw; a.ksteps = B.f_ksteps;
+            a.TH = B.f_TH; a.TWo = B.f_TWo; a.tiles_x = B.f_tiles_x; a.tiles_y = B.f_tiles_y; a.CC = B.f_CC;
+            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds;
+            nparts = B.f_tiles_x * B.f_tiles_y;
+            snprintf(nm, sizeof nm, "b%d.mbconv", i);
+            char fl[48];
+            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps);
+            STEP(nm, fl, launch_mbconv_a(a, st));
+        } else {
+            const _Float16* dw_in = x;
+            if (B.has_expand) {
+                snprintf(nm, sizeof nm, "b%d.expand", i);
+                STEP(nm, gemm_label(B.expand, n * HWi, EPI_SILU, false, false),
+                     run_gemm(B.expand, x, n * HWi, bb->expbuf, EPI_SILU, nullptr, HWi, nullptr, nullptr, st));
+                if (bb->keep) { int r = save_act(bb, nm, bb->expbuf, (size_t)n * HWi * B.ce, true, st); if (r) return r; }
+                dw_in = bb->expbuf;
+            }
+            DwArgs d{};
+            d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = bb->dwbuf; d.pool_part = bb->pool_part;
+            d.B = n; d.H = B.H; d.W = B.H; d.C = B.ce; d.Ho = B.Ho; d.Wo = B.Ho; d.pad_t = B.pad; d.pad_l = B.pad;
+            d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts;
+            snprintf(nm, sizeof nm, "b%d.dw", i);
+            char dl[48];
+            snprintf(dl, sizeof dl, "dwconv<%d,%d,%d>", d.ks, d.stride, d.tw);
+            STEP(nm, dl, launch_dwconv(d, st));
         }
-        DwArgs d{};
-        d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = bb->dwbuf; d.pool_part = bb->pool_part;
-        d.B = n; d.H = B.H; d.W = B.H; d.C = B.ce; d.Ho = B.Ho; d.Wo = B.Ho; d.pad_t = B.pad; d.pad_l = B.pad;
-        d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts;
         snprintf(nm, sizeof nm, "b%d.dw", i);
-        STEP(nm, launch_dwconv(d, st));
         if (bb->keep) { int r = save_act(bb, nm, bb->dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        STEP(nm, launch_se_gate(bb->pool_part, B.parts, n, B.ce, B.cs, 1.0f / (float)HWo, B.se_wr, B.se_br, B.se_we,
+        STEP(nm, "se_gate", launch_se_gate(bb->pool_part, nparts, n, B.ce, B.cs, 1.0f / (float)HWo, B.se_wr, B.se_br, B.se_we,
                                 B.se_be, bb->gate, st));
         if (bb->keep) { int r = save_act(bb, nm, bb->gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
-        STEP(nm, run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
+        STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
         snprintf(nm, sizeof nm, "b%d.out", i);
         if (bb->keep) { int r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st); if (r) return r; }
         _Float16* t = x; x = y; y = t;
     }
     const int HWh = bb->blk[15].Ho * bb->blk[15].Ho;
-    STEP("head", run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
+    STEP("head", gemm_label(bb->head, n * HWh, EPI_GAP, false, false), run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
     bb->last_n = n;
 #undef STEP
     return 0;
@@ -489,7 +574,7 @@ extern "C" int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, 
 }
 
 extern "C" int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, float* out_features_dev,
-                                    void* hip_stream, char (*names)[48], float* ms, int* launches, int cap, int* n_out)
+                                    void* hip_stream, char (*names)[64], float* ms, int* launches, int cap, int* n_out)
 {
     if (!bb || !patches_dev || !out_features_dev || !names || !ms || !n_out)
         return fail(MMC_ERR_ARG, "NULL argument");
@@ -507,7 +592,7 @@ extern "C" int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, i
         hipEventDestroy(e.e0);
         hipEventDestroy(e.e1);
         if (cnt < cap) {
-            snprintf(names[cnt], 48, "%s", e.name.c_str());
+            snprintf(names[cnt], 64, "%s", e.name.c_str());
             ms[cnt] = t;
             if (launches) launches[cnt] = 1;
             ++cnt;

@@ -1,0 +1,63 @@
+"""Algorithmic work of every launch of the EfficientNet-B0 schedule (per batch of B patches).
+
+Used by bench.py for the roofline object and quoted in DESIGN.md.  "Algorithmic bytes" are the
+compulsory HBM bytes of the launch as scheduled: every input tensor read once, every output
+written once, weights once -- re-reads through caches are NOT counted (they show up as PMC
+``traffic`` above this figure).  Names match the launch names of ``mmc_backbone_profile``.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List, NamedTuple
+
+from .weights import B0_BLOCKS, FEATURE_DIM
+
+
+class Launch(NamedTuple):
+    name: str
+    kind: str          # stem | expand | dw | se | project | head
+    bytes: int         # algorithmic HBM bytes
+    flops: int         # 2*MAC (MFMA/VALU useful work)
+
+
+def b0_launches(batch: int) -> List[Launch]:
+    out: List[Launch] = []
+    h = 112
+    out.append(Launch("stem", "stem", batch * (224 * 224 * 3 + h * h * 32 * 2) + 32 * 32 * 2,
+                      2 * batch * h * h * 32 * 27))
+    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+        ce = cin * e
+        cs = max(1, cin // 4)
+        ho = -(-h // s)
+        m_in, m_out = batch * h * h, batch * ho * ho
+        if e != 1:
+            out.append(Launch(f"b{i}.expand", "expand", m_in * (cin + ce) * 2 + ce * cin * 2, 2 * m_in * cin * ce))
+            # fused alternative (mbconv_a_kernel): the expanded tensor never reaches HBM
+            out.append(Launch(f"b{i}.mbconv", "mbconv", m_in * cin * 2 + m_out * ce * 2 + ce * cin * 2 + k * k * ce * 4,
+                              2 * m_in * cin * ce + 2 * m_out * ce * k * k))
+        out.append(Launch(f"b{i}.dw", "dw", (m_in + m_out) * ce * 2 + k * k * ce * 4, 2 * m_out * ce * k * k))
+        out.append(Launch(f"b{i}.gate", "se", batch * ce * 4 * 2 + 2 * cs * ce * 4, 2 * batch * 2 * cs * ce))
+        res = m_out * cout * 2 if (s == 1 and cin == cout) else 0
+        out.append(Launch(f"b{i}.project", "project", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2,
+                          2 * m_out * ce * cout))
+        h = ho
+    out.append(Launch("head", "head", batch * h * h * 320 * 2 + batch * FEATURE_DIM * 4 + FEATURE_DIM * 320 * 2,
+                      2 * batch * h * h * 320 * FEATURE_DIM))
+    return out
+
+
+def totals(batch: int, launched=None) -> Dict[str, float]:
+    """Totals over the launches actually issued (names from mmc_backbone_profile); default = unfused."""
+    ls = b0_launches(batch)
+    if launched is not None:
+        names = set(launched)
+        ls = [l for l in ls if l.name in names]
+    else:
+        ls = [l for l in ls if l.kind != "mbconv"]
+    return {"bytes": float(sum(l.bytes for l in ls)), "flops": float(sum(l.flops for l in ls)),
+            "bytes_per_patch": sum(l.bytes for l in ls) / batch, "flops_per_patch": sum(l.flops for l in ls) / batch}
+
+
+# MI355X peaks used to normalise (from /opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0          # 8 TB/s spec (6.3 TB/s achievable by a streaming copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16

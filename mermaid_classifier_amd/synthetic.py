@@ -1,0 +1,90 @@
+"""Seeded synthetic EfficientNet-B0 weights in the pyspacer/lukemelas key layout.
+
+No real ``efficientnet.pt`` exists offline, so bench.py, smoke() and the tests all run on these.
+Conv weights ~ N(0, 1/fan_in) (squeeze-excite x2), BN gamma ~ U(0.6,1.4), beta ~ N(0,0.25),
+biases ~ N(0,0.3), all from ``numpy.random.default_rng(seed)`` (stable across machines).  BN
+running statistics come from ``bn_stats`` -- the calibrated statistics committed as
+tests/golden/synth_bn_stats.npz (computed once by the oracle, tests/golden/make_golden.py) --
+so that, like a trained net, activations stay O(1) through all 16 blocks.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from .weights import B0_BLOCKS, FEATURE_DIM
+
+NUM_FC_CLASSES = 1275  # pyspacer builds the net with num_classes=1275 [RECALL R3]; _fc is unused
+
+
+def checkpoint_keys() -> Dict[str, tuple]:
+    """Every key of the checkpoint's state dict (without ``module.``), in module order."""
+    keys: Dict[str, tuple] = {}
+
+    def bn(prefix: str, c: int):
+        keys[prefix + ".weight"] = (c,)
+        keys[prefix + ".bias"] = (c,)
+        keys[prefix + ".running_mean"] = (c,)
+        keys[prefix + ".running_var"] = (c,)
+        keys[prefix + ".num_batches_tracked"] = ()
+
+    keys["_conv_stem.weight"] = (32, 3, 3, 3)
+    bn("_bn0", 32)
+    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+        p = f"_blocks.{i}."
+        ce = cin * e
+        if e != 1:
+            keys[p + "_expand_conv.weight"] = (ce, cin, 1, 1)
+            bn(p + "_bn0", ce)
+        keys[p + "_depthwise_conv.weight"] = (ce, 1, k, k)
+        bn(p + "_bn1", ce)
+        cs = max(1, int(cin * 0.25))
+        keys[p + "_se_reduce.weight"] = (cs, ce, 1, 1)
+        keys[p + "_se_reduce.bias"] = (cs,)
+        keys[p + "_se_expand.weight"] = (ce, cs, 1, 1)
+        keys[p + "_se_expand.bias"] = (ce,)
+        keys[p + "_project_conv.weight"] = (cout, ce, 1, 1)
+        bn(p + "_bn2", cout)
+    keys["_conv_head.weight"] = (FEATURE_DIM, 320, 1, 1)
+    bn("_bn1", FEATURE_DIM)
+    keys["_fc.weight"] = (NUM_FC_CLASSES, FEATURE_DIM)
+    keys["_fc.bias"] = (NUM_FC_CLASSES,)
+    return keys
+
+
+def synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
+    """{key: ndarray}; running stats default to mean 0 / var 1 unless ``bn_stats`` supplies them."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    for k, shp in checkpoint_keys().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = np.zeros((), dtype=np.int64)
+        elif k.endswith("running_mean"):
+            sd[k] = np.zeros(shp, dtype=np.float32)
+        elif k.endswith("running_var"):
+            sd[k] = np.ones(shp, dtype=np.float32)
+        elif ("_bn" in k) and k.endswith(".weight"):
+            sd[k] = rng.uniform(0.6, 1.4, shp).astype(np.float32)
+        elif ("_bn" in k) and k.endswith(".bias"):
+            sd[k] = rng.normal(0, 0.25, shp).astype(np.float32)
+        elif k.endswith(".bias"):
+            sd[k] = rng.normal(0, 0.3, shp).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            std = np.sqrt(1.0 / fan_in) * (2.0 if "_se_" in k else 1.0)
+            sd[k] = rng.normal(0, std, shp).astype(np.float32)
+    if bn_stats is not None:
+        for k, v in bn_stats.items():
+            if k not in sd or tuple(sd[k].shape) != tuple(np.shape(v)):
+                raise KeyError(f"bn_stats entry {k!r} does not match the B0 layout")
+            sd[k] = np.asarray(v, dtype=np.float32).copy()
+    return sd
+
+
+def save_checkpoint(sd: Dict[str, np.ndarray], path_or_buf) -> None:
+    """Write ``sd`` the way pyspacer's efficientnet.pt is laid out [RECALL R1]:
+    ``torch.save({'net': {'module.<key>': tensor}})``."""
+    import torch
+    torch.save({"net": {"module." + k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()}}, path_or_buf)

@@ -181,41 +181,17 @@ def make_synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.nda
                               calib_patches: Optional[np.ndarray] = None) -> Dict[str, torch.Tensor]:
     """Seeded synthetic B0 weights in the lukemelas/pyspacer key layout.
 
-    Conv weights ~ N(0, gain/fan_in) from ``numpy.random.default_rng(seed)`` (stable
-    across machines); BN gamma ~ U(0.6,1.4), beta ~ N(0,0.25).  BN running statistics
+    The random part comes from mermaid_classifier_amd.synthetic (numpy default_rng(seed),
+    stable across machines); this function adds the calibration.  BN running statistics
     are *calibrated*: like a trained net, running_mean/var track the statistics of the
     layer's input on a fixed calibration mixture, so activations stay O(1)
     through all 16 blocks instead of exploding or dying.  The calibrated statistics
     are data (tests/golden/synth_bn_stats.npz) so that every machine builds exactly
     the same weights; pass ``bn_stats=None`` to recompute them with ``calib_patches``.
     """
-    rng = np.random.default_rng(seed)
-    shapes = expected_keys()
-    sd: Dict[str, torch.Tensor] = {}
-    for k, shp in shapes.items():
-        if k.endswith("num_batches_tracked"):
-            sd[k] = torch.tensor(0, dtype=torch.long)
-        elif k.endswith("running_mean"):
-            sd[k] = torch.zeros(shp)
-        elif k.endswith("running_var"):
-            sd[k] = torch.ones(shp)
-        elif ("_bn" in k) and k.endswith(".weight"):
-            sd[k] = torch.from_numpy(rng.uniform(0.6, 1.4, shp).astype(np.float32))
-        elif ("_bn" in k) and k.endswith(".bias"):
-            sd[k] = torch.from_numpy(rng.normal(0, 0.25, shp).astype(np.float32))
-        elif k.endswith(".bias"):
-            sd[k] = torch.from_numpy(rng.normal(0, 0.3, shp).astype(np.float32))
-        else:
-            fan_in = int(np.prod(shp[1:]))
-            std = np.sqrt(1.0 / fan_in)
-            if "_se_" in k:
-                std *= 2.0
-            sd[k] = torch.from_numpy(rng.normal(0, std, shp).astype(np.float32))
+    from mermaid_classifier_amd.synthetic import synthetic_state_dict  # one generator for product and oracle
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_state_dict(seed, bn_stats).items()}
     if bn_stats is not None:
-        for k, v in bn_stats.items():
-            if k not in sd or tuple(sd[k].shape) != tuple(v.shape):
-                raise KeyError(f"bn_stats entry {k!r} does not match the B0 layout")
-            sd[k] = torch.from_numpy(np.asarray(v, dtype=np.float32).copy())
         return sd
     # ---- calibrate BN running stats on data, layer by layer --------------------
     if calib_patches is None:

@@ -11,14 +11,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def kept_backbone(checkpoint_path):
+@pytest.fixture(scope="module", params=["fused", "unfused"])
+def kept_backbone(checkpoint_path, request):
+    """fused: expand+depthwise in one kernel (the product schedule; the expanded tensor is never in
+    HBM, so there is no ``b<i>.expand`` tensor to compare).  unfused: MMC_FUSE=0, every tensor."""
     os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
+    if request.param == "unfused":
+        os.environ["MMC_FUSE"] = "0"
     try:
         from mermaid_classifier_amd.backbone import Backbone
         bb = Backbone(str(checkpoint_path), device=0, max_batch=4)
     finally:
         os.environ.pop("MMC_KEEP_ACTIVATIONS", None)
+        os.environ.pop("MMC_FUSE", None)
+    bb.mode = request.param
     yield bb
     bb.close()
 
@@ -33,7 +39,7 @@ def test_every_intermediate_matches_oracle(kept_backbone, oracle_net, kind):
     report = []
     worst = 0.0
     for name, t in taps.items():
-        if name == "features":
+        if name == "features" or (kept_backbone.mode == "fused" and name.endswith(".expand")):
             continue
         o = t.numpy()
         if o.ndim == 4 and name.endswith(".gate"):
@@ -46,6 +52,7 @@ def test_every_intermediate_matches_oracle(kept_backbone, oracle_net, kind):
         report.append(f"{name:12s} rel_rms={err:.2e} maxabs={mx:.3e}")
         worst = max(worst, err)
     print("\n".join(report))
+    assert len(report) == (49 if kept_backbone.mode == "fused" else 64)
     depth_tol = 2e-2 if kind == "noise" else 1e-2
     assert worst < depth_tol, "\n".join(report)
     rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
