@@ -42,9 +42,9 @@ struct MbArgs {
     _Float16* out;          // [B][Ho][Wo][Ce]
     float* pool_part;       // [B][tiles][Ce]
     int B, H, W, Cin, Ce, Ho, Wo, pad;
-    int ks, stride, tw, ksteps;
+    int ks, stride, tw, ksteps, npair;
     int TH, TWo, tiles_x, tiles_y, CC, CCG, S;
-    int red_off, lds_bytes;
+    int wl_off, red_off, lds_bytes;
 };
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
@@ -53,7 +53,7 @@ int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, co
 int launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 int launch_dwconv(const DwArgs& a, hipStream_t st);
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs, float inv_hw, const float* Wr,
-                   const float* br, const float* We, const float* be, float* gate, hipStream_t st);
+                   const float* br, const float* WeT, const float* be, float* rbuf, float* gate, hipStream_t st);
 int launch_mlp_layer(const float* X, int M, int K, const float* W, const float* bias, float* Y, int N, bool relu,
                      hipStream_t st);
 int launch_calibrate(const float* logits, int M, int K, const float* a, const float* b, float* proba, int32_t* argmax,

@@ -118,29 +118,36 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 // Pointwise (1x1) convolution as an MFMA GEMM:  Y[m][n] = epi( sum_k X[m][k] * W[n][k] + bias[n] ).
 // Operands are swapped (weights = MFMA A operand, activations = B operand) so that the fp32 result
 // fragment holds, per lane, 4*NT CONSECUTIVE output channels of one pixel -> 8-byte stores that
-// coalesce to full lines.  The host packs W row-permuted per chunk of 16*NT channels:
-//   packed row (chunk*16NT + t*16 + 4q + j)  <->  channel (chunk*16NT + q*4NT + 4t + j).
-// Each wave owns MT fragments of 16 rows (pixels); a workgroup is 4 waves = 64*MT rows;
-// blockIdx.y selects the channel chunk.  Activation fragments are loaded straight from HBM/L2 into
-// registers (16 B per lane); weight fragments come through L1/L2 (weights are small and shared).
+// coalesce to full lines.  Within a chunk of 16*NT channels the host permutes weight rows:
+//   fragment row (t*16 + 4q + j)  <->  channel (chunk*16NT + q*4NT + 4t + j).
+// Weights are packed on the host in FRAGMENT ORDER: the 1 KB a wave feeds to one MFMA (16 rows x
+// 32 k, lane-linear) is contiguous, at ((chunk*KS32 + kstep)*NT + t) KB.  A workgroup (4 waves,
+// 64*MT rows, one chunk) stages UK k-steps of weight fragments per batch through LDS with perfectly
+// coalesced 16-byte copies, so each fragment leaves L2 once per workgroup instead of once per wave,
+// and reads them back with conflict-free lane-linear ds_read_b128.  Activation fragments go straight
+// from HBM/L2 to registers (each wave owns its rows), one batch ahead of the MFMAs.
 // EPI_SILU   : y = silu(acc+bias)                              (expand conv)
 // EPI_LINEAR : y = acc+bias (+ residual)                       (project conv), optional SE gate on X
 // EPI_GAP    : out[patch][n] = mean over the patch's HW rows of silu(acc+bias)   (head conv + avgpool)
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI, bool GATE, bool RES>
+template <int MT, int NT, int EPI, bool GATE, bool RES, int UK>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict__ X, int M, int K,
-                                                      const _Float16* __restrict__ Wp, int Kp,
-                                                      const float* __restrict__ bias,  // natural channel order, zero padded to [Np]
+                                                      const _Float16* __restrict__ Wp, int KS32,
+                                                      const float* __restrict__ bias,  // natural channel order, zero padded
                                                       _Float16* __restrict__ Y, int N,
                                                       const float* __restrict__ gate,  // [patch][K] fp32
                                                       int HW,
                                                       const _Float16* __restrict__ res,
                                                       float* __restrict__ gap_out, float inv_hw)
 {
+    constexpr int NFRAG = UK * NT;             // weight fragments per batch
+    constexpr int NPASS = (NFRAG + 3) / 4;     // 4 waves copy one fragment each per pass
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[NFRAG * 512];
+    __shared__ float red[EPI == EPI_GAP ? 4 * 16 * NT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int chunk = blockIdx.y;
-    const _Float16* wbase = Wp + ((size_t)chunk * 16 * NT + m) * Kp + q * 8;
+    const _Float16* wsrc = Wp + (size_t)chunk * KS32 * NT * 512 + lane * 8;
     int row[MT];
     bool rok[MT];
     int gpatch[MT];
@@ -164,33 +171,77 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = (f4){0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < Kp; k0 += 32) {
-        const int k = k0 + q * 8;
-        const bool kok = k < K;
-        h8 xf[MT];
+    const int nbatch = (KS32 + UK - 1) / UK;
+    uint4 wst[NPASS];   // weight staging registers (global -> regs -> LDS)
+    h8 xf[UK][MT];      // activation fragments of the current batch
+    auto load_w = [&](int bt) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kok && rok[i]) v = *reinterpret_cast<const h8*>(X + (size_t)row[i] * K + k);
-            if (GATE) {
-                if (kok && rok[i]) {
-                    const f4 g0 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k);
-                    const f4 g1 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k + 4);
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int f = ps * 4 + wave;                 // fragment index inside the batch: u*NT + t
+            const int ks = bt * UK + f / NT;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (f < NFRAG && ks < KS32)
+                v = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(bt * UK) * NT + f) * 512);
+            wst[ps] = v;
+        }
+    };
+    auto load_x = [&](int bt, h8 (&dst)[UK][MT]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = (_Float16)((float)v[j] * g0[j]);
-                        v[4 + j] = (_Float16)((float)v[4 + j] * g1[j]);
+        for (int u = 0; u < UK; ++u) {
+            const int k = (bt * UK + u) * 32 + q * 8;
+            const bool kok = k < K;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kok && rok[i]) v = *reinterpret_cast<const h8*>(X + (size_t)row[i] * K + k);
+                if (GATE) {
+                    if (kok && rok[i]) {
+                        const f4 g0 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k);
+                        const f4 g1 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = (_Float16)((float)v[j] * g0[j]);
+                            v[4 + j] = (_Float16)((float)v[4 + j] * g1[j]);
+                        }
                     }
                 }
+                dst[u][i] = v;
             }
-            xf[i] = v;
+        }
+    };
+    load_w(0);
+    load_x(0, xf);
+    for (int bt = 0; bt < nbatch; ++bt) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int f = ps * 4 + wave;
+            if (f < NFRAG) *reinterpret_cast<uint4*>(wlds + f * 512 + lane * 8) = wst[ps];
+        }
+        __syncthreads();
+        h8 xn[UK][MT];
+        const bool more = bt + 1 < nbatch;
+        if (more) {  // next batch's global loads fly during this batch's MFMAs
+            load_w(bt + 1);
+            load_x(bt + 1, xn);
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const h8 wf = *reinterpret_cast<const h8*>(wbase + (size_t)t * 16 * Kp + k0);
+        for (int u = 0; u < UK; ++u) {
+            if (bt * UK + u < KS32) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[i], acc[i][t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const h8 wf = *reinterpret_cast<const h8*>(wlds + (u * NT + t) * 512 + lane * 8);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[u][i], acc[i][t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < UK; ++u)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) xf[u][i] = xn[u][i];
         }
     }
     // epilogue: lane (m,q) holds channels cbase + q*4NT + 4t + j of pixel row[i]
@@ -203,7 +254,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
         for (int j = 0; j < 4; ++j) bs[t][j] = bv[j];
     }
     if (EPI == EPI_GAP) {
-        __shared__ float red[4][16 * NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -213,11 +263,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                if (m == 0) red[wave][q * 4 * NT + 4 * t + j] = v;
+                if (m == 0) red[wave * 16 * NT + q * 4 * NT + 4 * t + j] = v;
             }
         __syncthreads();
         if (tid < 16 * NT) {
-            const float s = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * inv_hw;
+            const float s = ((red[tid] + red[16 * NT + tid]) + (red[32 * NT + tid] + red[48 * NT + tid])) * inv_hw;
             const int c = chunk * 16 * NT + tid;
             if (c < N) gap_out[(size_t)blockIdx.x * N + c] = s;
         }
@@ -353,49 +403,80 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Squeeze-excite gate: one workgroup per patch.
+// Squeeze-excite gate in two launches (both latency-bound, so both spread over many waves):
+// se_reduce_kernel: one workgroup per patch; se_expand_kernel: one thread per (patch, channel).
 //   pooled[c] = inv_hw * sum_p pool_part[b][p][c]
 //   r[j]      = silu(b_r[j] + sum_c W_r[j][c] pooled[c])        j < Cs   (wave-reduced dot products)
 //   gate[c]   = sigmoid(b_e[c] + sum_j W_e[c][j] r[j])      (W_e stored transposed, [Cs][C])
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
-                                                      float inv_hw, const float* __restrict__ Wr,
-                                                      const float* __restrict__ br, const float* __restrict__ WeT,
-                                                      const float* __restrict__ be, float* __restrict__ gate)
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
+                                                        float inv_hw, const float* __restrict__ Wr,
+                                                        const float* __restrict__ br, float* __restrict__ rout)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C] + r[Cs]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C]
     float* pooled = sm;
-    float* r = sm + C;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* pp = pool_part + (size_t)b * nparts * C;
     for (int c = tid; c < C; c += 256) {
-        float s = 0.f;
-        for (int p = 0; p < nparts; ++p) s += pp[(size_t)p * C + c];
-        pooled[c] = s * inv_hw;
-    }
-    __syncthreads();
-    // reduce FC: 16 groups of 16 lanes, one output j per group per round, 16-byte loads along C
-    const int g = tid >> 4, l = tid & 15;
-    for (int j = g; j < Cs; j += 16) {
-        float s = 0.f;
-        for (int c = l * 4; c < C; c += 64) {
-            const f4 w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + c);
-            const f4 x = *reinterpret_cast<const f4*>(pooled + c);
-            s += w[0] * x[0] + w[1] * x[1] + w[2] * x[2] + w[3] * x[3];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = 0;
+        for (; p + 3 < nparts; p += 4) {
+            s0 += pp[(size_t)p * C + c];
+            s1 += pp[(size_t)(p + 1) * C + c];
+            s2 += pp[(size_t)(p + 2) * C + c];
+            s3 += pp[(size_t)(p + 3) * C + c];
         }
-        s += __shfl_xor(s, 8);
-        s += __shfl_xor(s, 4);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 1);
-        if (l == 0) r[j] = silu_f(s + br[j]);
+        for (; p < nparts; ++p) s0 += pp[(size_t)p * C + c];
+        pooled[c] = ((s0 + s1) + (s2 + s3)) * inv_hw;
     }
     __syncthreads();
-    // expand FC: WeT is [Cs][C] so neighbouring lanes read neighbouring floats
-    for (int c = tid; c < C; c += 256) {
-        float s = be[c];
-        for (int j = 0; j < Cs; ++j) s += WeT[(size_t)j * C + c] * r[j];
-        gate[(size_t)b * C + c] = sigmoid_f(s);
+    // wave w owns outputs j = w, w+4, ...; lanes stride over C with 16-byte loads; 4 outputs in flight
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int j0 = wave; j0 < Cs; j0 += 16) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 4; c < C; c += 256) {
+            const f4 x = *reinterpret_cast<const f4*>(pooled + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                if (j < Cs) {
+                    const f4 w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + c);
+                    s[u] += (w[0] * x[0] + w[1] * x[1]) + (w[2] * x[2] + w[3] * x[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = s[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            const int j = j0 + 4 * u;
+            if (lane == 0 && j < Cs) rout[(size_t)b * Cs + j] = silu_f(v + br[j]);
+        }
     }
+}
+
+// gate[b][c] = sigmoid(be[c] + sum_j WeT[j][c] r[b][j]);  grid (C/256, B); WeT is [Cs][C] (coalesced)
+__global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ r, int C, int Cs,
+                                                        const float* __restrict__ WeT, const float* __restrict__ be,
+                                                        float* __restrict__ gate)
+{
+    __shared__ float rs[64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < Cs) rs[tid] = r[(size_t)b * Cs + tid];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + tid;
+    if (c >= C) return;
+    float s0 = be[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int j = 0;
+    for (; j + 3 < Cs; j += 4) {
+        s0 += WeT[(size_t)j * C + c] * rs[j];
+        s1 += WeT[(size_t)(j + 1) * C + c] * rs[j + 1];
+        s2 += WeT[(size_t)(j + 2) * C + c] * rs[j + 2];
+        s3 += WeT[(size_t)(j + 3) * C + c] * rs[j + 3];
+    }
+    for (; j < Cs; ++j) s0 += WeT[(size_t)j * C + c] * rs[j];
+    gate[(size_t)b * C + c] = sigmoid_f((s0 + s1) + (s2 + s3));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -543,19 +624,36 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ i
     dst[2] = w[2];
 }
 
+// fp16 x fp32 + fp32 -> fp32 in ONE VALU instruction (v_fma_mix_f32 reads the low/high half of a packed
+// fp16 pair directly): the depthwise taps need no v_cvt_f32_f16 at all.
+static __device__ __forceinline__ float fma_mix_lo(uint32_t h2, float w, float acc)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float acc)
+{
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused MBConv front half: expand 1x1 (+bias+SiLU) -> LDS -> depthwise KSxKS stride ST (+bias+SiLU)
 // -> fp16 NHWC to HBM, plus squeeze-excite partial sums.  The 6x-expanded tensor never leaves the CU.
 // One workgroup = (patch, output tile TH x TWo, chunk of CC expanded channels).
+//   phase 0: the chunk's depthwise taps go to LDS; every wave issues ALL its input-fragment loads
+//            (up to NPAIR pairs of 16-position fragments x KSTEPS) so one HBM latency covers the tile.
 //   phase 1: the tile's input window (halo included, clipped to the image) is P positions x Cin;
-//            each wave runs two 16-position MFMA fragments at a time against the chunk's weights
-//            (weights = A operand, positions = B operand) and writes silu(acc+bias) as fp16 into
-//            LDS E[position][CC] (row stride CC*2+16 bytes: 16-B aligned rows, spread over banks).
+//            weights = MFMA A operand (prefetched one 16-channel fragment ahead), positions = B
+//            operand; silu(acc+bias) is written as fp16 into LDS E[position][CC]
+//            (row stride CC*2+16 bytes: 16-B aligned rows, spread over banks).
 //   phase 2: the depthwise conv reads E with 16-byte LDS reads (8 channels x TW output pixels per
-//            thread, fp32 accumulate); image borders are handled by tap predication (the padding is
-//            zero in the expanded domain, so skipped taps are exact).
+//            thread) and accumulates in fp32 with v_fma_mix_f32; image borders are handled by tap
+//            predication (padding is zero in the expanded domain, so skipped taps are exact).
 // ---------------------------------------------------------------------------------------------
-template <int KS, int ST, int TW, int KSTEPS>
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR>
 __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
                                                        const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
                                                        const float* __restrict__ bexp,     // [Ce]
@@ -564,7 +662,8 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                                                        _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
                                                        float* __restrict__ pool_part,      // [B][ntiles][Ce]
                                                        int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
-                                                       int TWo, int tiles_x, int CC, int CCG, int S, int red_off)
+                                                       int TWo, int tiles_x, int CC, int CCG, int S, int wl_off,
+                                                       int red_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Kp = 32 * KSTEPS;
@@ -584,51 +683,70 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     const int P = (wy1 - wy0) * ww;
     const int ES = CC * 2 + 16;  // bytes per E row
     const int NTC = CC >> 4;
+    float* wl = reinterpret_cast<float*>(smem + wl_off);    // [KS*KS][CC] depthwise taps of this chunk
+    float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]
+    // ---------------- phase 0: issue every global load this workgroup needs ----------------
+    int p[NPAIR][2];
+    h8 xf[NPAIR][2][KSTEPS];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pp = ((pr * 4 + wave) * 2 + i) * 16 + m;
+            p[pr][i] = pp;
+            const bool ok = pp < P;
+            const int py = ok ? pp / ww : 0, px = ok ? pp - py * ww : 0;
+            const _Float16* xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok && ks * 32 + q * 8 < Cin) v = *reinterpret_cast<const h8*>(xp + ks * 32);
+                xf[pr][i][ks] = v;
+            }
+        }
+    for (int i = tid; i < KS * KS * CC; i += 256) {
+        const int tap = i / CC, c = i - tap * CC;
+        wl[i] = Wdw[(size_t)tap * Ce + chunk * CC + c];
+    }
     // ---------------- phase 1: expand GEMM into LDS ----------------
     {
-        const int MTn = (P + 15) >> 4;
         const _Float16* wbase = Wexp + ((size_t)chunk * CC + m) * Kp + q * 8;
         const float* bb = bexp + chunk * CC + 4 * q;
-        for (int mt = wave * 2; mt < MTn; mt += 8) {
-            int p[2];
-            bool pok[2];
-            h8 xf[2][KSTEPS];
+        h8 wn[KSTEPS];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                p[i] = (mt + i) * 16 + m;
-                pok[i] = p[i] < P;
-                const int py = p[i] / ww, px = p[i] - py * ww;
-                const _Float16* xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
+        for (int ks = 0; ks < KSTEPS; ++ks) wn[ks] = *reinterpret_cast<const h8*>(wbase + ks * 32);
+        for (int t = 0; t < NTC; ++t) {
+            h8 wc[KSTEPS];
 #pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (pok[i] && ks * 32 + q * 8 < Cin) v = *reinterpret_cast<const h8*>(xp + ks * 32);
-                    xf[i][ks] = v;
-                }
+            for (int ks = 0; ks < KSTEPS; ++ks) wc[ks] = wn[ks];
+            if (t + 1 < NTC) {
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks)
+                    wn[ks] = *reinterpret_cast<const h8*>(wbase + (size_t)(t + 1) * 16 * Kp + ks * 32);
             }
-            for (int t = 0; t < NTC; ++t) {
+            const f4 bv = *reinterpret_cast<const f4*>(bb + t * 16);
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                if (((pr * 4 + wave) * 2) * 16 >= P) continue;  // wave-uniform: no position in this pair
                 f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const h8 wf = *reinterpret_cast<const h8*>(wbase + (size_t)t * 16 * Kp + ks * 32);
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[0][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[1][ks], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xf[pr][0][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xf[pr][1][ks], a1, 0, 0, 0);
                 }
-                const f4 bv = *reinterpret_cast<const f4*>(bb + t * 16);
                 h4 o0, o1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     o0[j] = (_Float16)silu_f(a0[j] + bv[j]);
                     o1[j] = (_Float16)silu_f(a1[j] + bv[j]);
                 }
-                if (pok[0]) *reinterpret_cast<h4*>(smem + (size_t)p[0] * ES + (t * 16 + 4 * q) * 2) = o0;
-                if (pok[1]) *reinterpret_cast<h4*>(smem + (size_t)p[1] * ES + (t * 16 + 4 * q) * 2) = o1;
+                if (p[pr][0] < P) *reinterpret_cast<h4*>(smem + p[pr][0] * ES + (t * 16 + 4 * q) * 2) = o0;
+                if (p[pr][1] < P) *reinterpret_cast<h4*>(smem + p[pr][1] * ES + (t * 16 + 4 * q) * 2) = o1;
             }
         }
     }
     __syncthreads();
     // ---------------- phase 2: depthwise from LDS ----------------
-    float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]
     const bool active = tid < CCG * S;
     const int cg = tid % CCG, s = tid / CCG;
     const int cglob = chunk * CC + cg * 8;
@@ -663,25 +781,28 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 float wk[KS][8];
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
-                    const f4 w0 = *reinterpret_cast<const f4*>(Wdw + (size_t)(ky * KS + kx) * Ce + cglob);
-                    const f4 w1 = *reinterpret_cast<const f4*>(Wdw + (size_t)(ky * KS + kx) * Ce + cglob + 4);
+                    const f4 w0 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8);
+                    const f4 w1 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
                 }
 #pragma unroll
                 for (int xr = 0; xr < NX; ++xr) {
                     const int ix = ox * ST - pad + xr;
-                    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (ix >= 0 && ix < W) v = *reinterpret_cast<const h8*>(smem + (rbase + ix) * ES + cg * 16);
-                    float vf[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vf[j] = (float)v[j];
+                    uint4 v = {0u, 0u, 0u, 0u};
+                    if (ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(smem + (rbase + ix) * ES + cg * 16);
 #pragma unroll
                     for (int t = 0; t < TW; ++t) {
                         const int kx = xr - t * ST;
                         if (kx >= 0 && kx < KS) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[t][j] = __builtin_fmaf(vf[j], wk[kx][j], acc[t][j]);
+                            acc[t][0] = fma_mix_lo(v.x, wk[kx][0], acc[t][0]);
+                            acc[t][1] = fma_mix_hi(v.x, wk[kx][1], acc[t][1]);
+                            acc[t][2] = fma_mix_lo(v.y, wk[kx][2], acc[t][2]);
+                            acc[t][3] = fma_mix_hi(v.y, wk[kx][3], acc[t][3]);
+                            acc[t][4] = fma_mix_lo(v.z, wk[kx][4], acc[t][4]);
+                            acc[t][5] = fma_mix_hi(v.z, wk[kx][5], acc[t][5]);
+                            acc[t][6] = fma_mix_lo(v.w, wk[kx][6], acc[t][6]);
+                            acc[t][7] = fma_mix_hi(v.w, wk[kx][7], acc[t][7]);
                         }
                     }
                 }
@@ -730,11 +851,12 @@ int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, co
 template <int MT, int NT>
 static int launch_gemm_nt(const GemmArgs& a, hipStream_t st)
 {
+    constexpr int UK = (MT * NT <= 4) ? 4 : 2;  // prefetch depth bounded by registers
     const int rows_per_wg = 64 * MT;
     dim3 grid((a.M + rows_per_wg - 1) / rows_per_wg, a.n_chunks, 1);
     dim3 block(256);
 #define GEMM_GO(EPI, GATE, RES)                                                                                    \
-    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, EPI, GATE, RES>), grid, block, 0, st, a.X, a.M, a.K, a.Wp, a.Kp,   \
+    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, EPI, GATE, RES, UK>), grid, block, 0, st, a.X, a.M, a.K, a.Wp, a.Kp / 32,   \
                        a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw)
     if (a.epi == EPI_SILU) GEMM_GO(EPI_SILU, false, false);
     else if (a.epi == EPI_LINEAR) {
@@ -752,8 +874,8 @@ template <int NT>
 static int launch_gap_nt(const GemmArgs& a, hipStream_t st)
 {
     dim3 grid(a.M / a.HW, a.n_chunks, 1);
-    hipLaunchKernelGGL((pw_gemm_kernel<1, NT, EPI_GAP, false, false>), grid, dim3(256), 0, st, a.X, a.M, a.K, a.Wp,
-                       a.Kp, a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw);
+    hipLaunchKernelGGL((pw_gemm_kernel<1, NT, EPI_GAP, false, false, (NT <= 4 ? 4 : 2)>), grid, dim3(256), 0, st, a.X, a.M, a.K, a.Wp,
+                       a.Kp / 32, a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw);
     LAUNCH_CHECK();
     return 0;
 }
@@ -819,11 +941,13 @@ int launch_dwconv(const DwArgs& a, hipStream_t st)
 }
 
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs, float inv_hw, const float* Wr,
-                   const float* br, const float* We, const float* be, float* gate, hipStream_t st)
+                   const float* br, const float* WeT, const float* be, float* rbuf, float* gate, hipStream_t st)
 {
-    const size_t shm = (size_t)(C + Cs) * sizeof(float);
-    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), shm, st, pool_part, nparts, C, Cs, inv_hw, Wr, br, We, be,
-                       gate);
+    if (Cs > 64) return -6;
+    hipLaunchKernelGGL(se_reduce_kernel, dim3(B), dim3(256), (size_t)C * sizeof(float), st, pool_part, nparts, C, Cs,
+                       inv_hw, Wr, br, rbuf);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(se_expand_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, rbuf, C, Cs, WeT, be, gate);
     LAUNCH_CHECK();
     return 0;
 }
@@ -857,32 +981,33 @@ int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int 
     return 0;
 }
 
-template <int KS, int ST, int TW, int KSTEPS>
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR>
 static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
 {
     dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, a.B);
-    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp, a.bexp,
-                       a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH, a.TWo,
-                       a.tiles_x, a.CC, a.CCG, a.S, a.red_off);
+    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp,
+                       a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH, a.TWo,
+                       a.tiles_x, a.CC, a.CCG, a.S, a.wl_off, a.red_off);
     LAUNCH_CHECK();
     return 0;
 }
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st)
 {
-#define MB_CASE(KS, ST, TW, KSTEPS) \
-    if (a.ks == KS && a.stride == ST && a.tw == TW && a.ksteps == KSTEPS) return launch_mbconv_t<KS, ST, TW, KSTEPS>(a, st);
-    MB_CASE(3, 2, 4, 1)
-    MB_CASE(3, 1, 7, 1)
-    MB_CASE(5, 2, 7, 1)
-    MB_CASE(5, 1, 7, 2)
-    MB_CASE(3, 2, 7, 2)
-    MB_CASE(3, 1, 7, 3)
-    MB_CASE(5, 1, 7, 3)
-    MB_CASE(5, 1, 7, 4)
-    MB_CASE(5, 2, 7, 4)
-    MB_CASE(5, 1, 7, 6)
-    MB_CASE(3, 1, 7, 6)
+#define MB_CASE(KS, ST, TW, KSTEPS, NPAIR)                                                          \
+    if (a.ks == KS && a.stride == ST && a.tw == TW && a.ksteps == KSTEPS && a.npair == NPAIR)       \
+        return launch_mbconv_t<KS, ST, TW, KSTEPS, NPAIR>(a, st);
+    MB_CASE(3, 2, 2, 1, 3)
+    MB_CASE(3, 1, 2, 1, 2)
+    MB_CASE(5, 2, 2, 1, 3)
+    MB_CASE(5, 1, 2, 2, 3)
+    MB_CASE(3, 2, 2, 2, 2)
+    MB_CASE(3, 1, 2, 3, 2)
+    MB_CASE(5, 1, 2, 3, 2)
+    MB_CASE(5, 1, 2, 4, 2)
+    MB_CASE(5, 2, 1, 4, 2)
+    MB_CASE(5, 1, 1, 6, 1)
+    MB_CASE(3, 1, 1, 6, 1)
 #undef MB_CASE
     return -5;
 }

@@ -73,9 +73,20 @@ struct PwLayer {
     float* b = nullptr;     // device [n_chunks*16*nt]
 };
 
-static int pick_nt(int N)
+// Channel fragments (16 wide) per workgroup.  Big-M layers (early blocks) take the widest chunk that
+// divides N (X is read once per chunk).  Small-M layers (14x14 and 7x7 blocks, head) take narrow
+// chunks: more workgroups and registers left for a 4-step-deep fragment prefetch; X re-reads hit L2.
+static int pick_nt(int N, bool small_m)
 {
     const int tiles = (N + 15) / 16;
+    if (small_m) {
+        int best = 4, waste = 1 << 30;
+        for (int nt = 4; nt >= 2; --nt) {
+            const int w = (tiles + nt - 1) / nt * nt - tiles;
+            if (w < waste) { waste = w; best = nt; }
+        }
+        return tiles <= 4 ? tiles : best;
+    }
     for (int nt = 8; nt >= 1; --nt)
         if (tiles % nt == 0) return nt;
     return 1;
@@ -94,16 +105,17 @@ struct BlockW {
     bool fused = false;
     _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
     int f_TH = 0, f_TWo = 0, f_CC = 0, f_tw = 0, f_ksteps = 0, f_CCG = 0, f_S = 0, f_tiles_x = 0, f_tiles_y = 0,
-        f_red_off = 0, f_lds = 0;
+        f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0;
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
 // chosen so that E[P][CC] + the pool scratch stay <= 64 KB of LDS (>= 2 workgroups per CU) while
 // the halo recompute and the per-chunk re-read of the (small) block input stay low.
-struct FuseCfg { int TH, TWo, CC; };
+struct FuseCfg { int TH, TWo, CC, TW; };
 static const FuseCfg B0_FUSE[16] = {
-    {0, 0, 0},     {8, 8, 48},    {8, 14, 48},   {7, 7, 48},   {14, 14, 48},  {7, 7, 48},    {14, 14, 96},  {14, 14, 96},
-    {14, 14, 96},  {14, 14, 96},  {14, 14, 96},  {7, 7, 96},   {7, 7, 192},   {7, 7, 192},   {7, 7, 192},   {7, 7, 192}};
+    {0, 0, 0, 0},     {8, 8, 48, 2},    {14, 14, 48, 2},  {4, 14, 48, 2},   {14, 14, 48, 2},  {2, 14, 80, 2},
+    {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {7, 7, 96, 1},
+    {7, 7, 192, 1},   {7, 7, 192, 1},   {7, 7, 192, 1},   {7, 7, 192, 1}};
 
 struct Saved {
     void* dev = nullptr;
@@ -120,7 +132,7 @@ struct mmc_backbone {
     PwLayer head;
     // workspace
     _Float16 *act0 = nullptr, *act1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
-    float *pool_part = nullptr, *gate = nullptr;
+    float *pool_part = nullptr, *gate = nullptr, *se_r = nullptr;
     uint8_t* in_stage = nullptr;
     float* out_stage = nullptr;
     size_t ws_bytes = 0;
@@ -177,27 +189,35 @@ static int dev_upload(mmc_backbone* bb, T** p, const std::vector<T>& host)
     return 0;
 }
 
-// Pack a natural [N][K] fp32 1x1-conv weight into the row-permuted, zero-padded fp16 layout of
-// pw_gemm_kernel: packed row (chunk*16nt + t*16 + 4q + j) <- channel (chunk*16nt + q*4nt + 4t + j).
+// Pack a natural [N][K] fp32 1x1-conv weight into the fragment-ordered fp16 layout of pw_gemm_kernel:
+// fragment (chunk, kstep, t) = 1 KB at ((chunk*KS32 + kstep)*nt + t)*512 halves; inside it lane
+// (q*16 + m) holds W[channel(chunk, t, m)][kstep*32 + q*8 .. +8], with the row permutation
+// fragment row (t*16 + 4qr + jr) <- channel (chunk*16nt + qr*4nt + 4t + jr).
 static int pack_pw(mmc_backbone* bb, PwLayer* L, const float* w, const float* b, int N, int K, int force_nt)
 {
     L->N = N;
     L->K = K;
     L->Kp = (K + 31) / 32 * 32;
-    L->nt = force_nt > 0 ? force_nt : pick_nt(N);
+    L->nt = force_nt > 0 ? force_nt : pick_nt(N, false);
     const int cw = 16 * L->nt;
     L->n_chunks = (N + cw - 1) / cw;
     const int Np = L->n_chunks * cw;
+    const int ks32 = L->Kp / 32;
     std::vector<_Float16> wp((size_t)Np * L->Kp, (_Float16)0.0f);
     std::vector<float> bp(Np, 0.0f);
     for (int ch = 0; ch < L->n_chunks; ++ch)
-        for (int t = 0; t < L->nt; ++t)
-            for (int q = 0; q < 4; ++q)
-                for (int j = 0; j < 4; ++j) {
-                    const int prow = ch * cw + t * 16 + 4 * q + j;
-                    const int c = ch * cw + q * 4 * L->nt + 4 * t + j;
+        for (int ks = 0; ks < ks32; ++ks)
+            for (int t = 0; t < L->nt; ++t)
+                for (int m = 0; m < 16; ++m) {
+                    const int c = ch * cw + (m >> 2) * 4 * L->nt + 4 * t + (m & 3);
                     if (c >= N) continue;
-                    for (int k = 0; k < K; ++k) wp[(size_t)prow * L->Kp + k] = (_Float16)w[(size_t)c * K + k];
+                    for (int q = 0; q < 4; ++q)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = ks * 32 + q * 8 + j;
+                            if (k >= K) continue;
+                            const size_t off = ((((size_t)ch * ks32 + ks) * L->nt + t) * 64 + (q * 16 + m)) * 8 + j;
+                            wp[off] = (_Float16)w[(size_t)c * K + k];
+                        }
                 }
     for (int c = 0; c < N; ++c) bp[c] = b[c];
     int r = dev_upload(bb, &L->w, wp);
@@ -325,7 +345,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             snprintf(nm, sizeof nm, "b%d.project", i);
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
-            TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, 0));
+            TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0));
         }
         // depthwise geometry
         B.tw = (B.Ho % 4 == 0) ? 4 : (B.Ho % 7 == 0 && B.Ho <= 7 ? 7 : 2);
@@ -342,11 +362,11 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 snprintf(key, sizeof key, "%d:", i);
                 const char* hit = strstr(ov, key);
                 while (hit && hit != ov && hit[-1] != ';') hit = strstr(hit + 1, key);
-                if (hit) sscanf(hit + strlen(key), "%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC);
+                if (hit) sscanf(hit + strlen(key), "%d,%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC, &fc.TW);
             }
             if (fc.TH > 0 && B.Ho % fc.TH == 0 && B.Ho % fc.TWo == 0 && B.ce % fc.CC == 0 && fc.CC % 16 == 0) {
                 B.f_TH = fc.TH; B.f_TWo = fc.TWo; B.f_CC = fc.CC;
-                B.f_tw = fc.TWo % 7 == 0 ? 7 : 4;
+                B.f_tw = fc.TW;
                 B.f_ksteps = (B.d.cin + 31) / 32;
                 B.f_CCG = fc.CC / 8;
                 B.f_S = 256 / B.f_CCG;
@@ -355,7 +375,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 if (wh > H) wh = H;
                 if (wwid > H) wwid = H;
                 const int ppad = (wh * wwid + 15) / 16 * 16;
-                B.f_red_off = ppad * (fc.CC * 2 + 16);
+                B.f_npair = (ppad / 16 + 7) / 8;
+                B.f_wl_off = ppad * (fc.CC * 2 + 16);
+                B.f_red_off = B.f_wl_off + B.d.k * B.d.k * fc.CC * 4;
                 B.f_lds = B.f_red_off + B.f_S * fc.CC * 4;
                 const int kp = 32 * B.f_ksteps;
                 if (B.f_lds <= 64 * 1024 && fc.TWo % B.f_tw == 0) {
@@ -379,7 +401,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     {
         TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
         TAKE(b, FEAT, "head.bias");
-        TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 8));
+        TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4));
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -392,6 +414,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     TRY_OR_FREE(dev_alloc(bb, &bb->dwbuf, mb * max_dw));
     TRY_OR_FREE(dev_alloc(bb, &bb->pool_part, mb * max_pool));
     TRY_OR_FREE(dev_alloc(bb, &bb->gate, mb * (size_t)max_c));
+    TRY_OR_FREE(dev_alloc(bb, &bb->se_r, mb * (size_t)64));
     TRY_OR_FREE(dev_alloc(bb, &bb->in_stage, mb * (size_t)IMG * IMG * 3));
     TRY_OR_FREE(dev_alloc(bb, &bb->out_stage, mb * (size_t)FEAT));
 #undef TAKE
@@ -479,11 +502,12 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
             a.pool_part = bb->pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
             a.Wo = B.Ho; a.pad = B.pad; a.ks = B.d.k; a.stride = B.d.s; a.tw = B.f_tw; a.ksteps = B.f_ksteps;
             a.TH = B.f_TH; a.TWo = B.f_TWo; a.tiles_x = B.f_tiles_x; a.tiles_y = B.f_tiles_y; a.CC = B.f_CC;
-            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds;
+            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair;
+            a.wl_off = B.f_wl_off;
             nparts = B.f_tiles_x * B.f_tiles_y;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char fl[48];
-            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps);
+            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair);
             STEP(nm, fl, launch_mbconv_a(a, st));
         } else {
             const _Float16* dw_in = x;
@@ -507,7 +531,7 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         if (bb->keep) { int r = save_act(bb, nm, bb->dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
         STEP(nm, "se_gate", launch_se_gate(bb->pool_part, nparts, n, B.ce, B.cs, 1.0f / (float)HWo, B.se_wr, B.se_br, B.se_we,
-                                B.se_be, bb->gate, st));
+                                B.se_be, bb->se_r, bb->gate, st));
         if (bb->keep) { int r = save_act(bb, nm, bb->gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
