@@ -25,6 +25,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division: results are rounded to fp16 anyway.
 static __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 static __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// Scaled-domain SiLU.  Every SiLU-activated tensor is stored as T' = log2(e) * T: the host folds
+// log2(e) into the producing convolution's weights and bias and 1/log2(e) into every consumer, so the
+// epilogue gets t = log2(e) * x straight out of the accumulator (bias = accumulator init) and
+//   log2(e) * silu(x) = t / (1 + 2^-t)   is v_exp_f32 (neg modifier) + v_add + v_rcp + v_mul.
+static __device__ __forceinline__ float silu_scaled(float t)
+{
+    return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stem: u8 HWC patch -> conv3x3 stride 2 (TF-same: pad right/bottom by 1) -> +bias -> SiLU -> fp16
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
         f4 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+            acc[t] = (f4){bs[t * 4], bs[t * 4 + 1], bs[t * 4 + 2], bs[t * 4 + 3]};  // bias = accumulator init
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], a, acc[t], 0, 0, 0);
         }
         const int oy = ty * 16 + oyl, ox = tx * 16 + m;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_f(acc[t][j] + bs[t * 4 + j]);
+            for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_scaled(acc[t][j]);
         *reinterpret_cast<h8*>(out + (((size_t)b * 112 + oy) * 112 + ox) * 32 + q * 8) = o;
     }
 }
@@ -165,11 +173,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
             gpatch[i] = GATE ? (rok[i] ? row[i] / HW : 0) : 0;
         }
     }
+    // bias is the accumulator's initial value: lane (m,q) owns channels cbase + 4t + j
+    const int cbase = chunk * 16 * NT + q * 4 * NT;
     f4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int t = 0; t < NT; ++t) {
+        const f4 bv = *reinterpret_cast<const f4*>(bias + cbase + 4 * t);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i][t] = bv;
+    }
 
     const int nbatch = (KS32 + UK - 1) / UK;
     uint4 wst[NPASS];   // weight staging registers (global -> regs -> LDS)
@@ -244,21 +256,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
                 for (int i = 0; i < MT; ++i) xf[u][i] = xn[u][i];
         }
     }
-    // epilogue: lane (m,q) holds channels cbase + q*4NT + 4t + j of pixel row[i]
-    const int cbase = chunk * 16 * NT + q * 4 * NT;
-    float bs[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f4 bv = *reinterpret_cast<const f4*>(bias + cbase + 4 * t);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bs[t][j] = bv[j];
-    }
+    // epilogue: lane (m,q) holds channels cbase + 4t + j of pixel row[i]; acc already includes the bias
     if (EPI == EPI_GAP) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = rok[0] ? silu_f(acc[0][t][j] + bs[t][j]) : 0.0f;
+                float v = rok[0] ? silu_scaled(acc[0][t][j]) : 0.0f;
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
@@ -282,10 +286,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
             if (c < N) {  // N is a multiple of 4
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[i][t][j] + bs[t][j];
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][t][j];
                 if (EPI == EPI_SILU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                    for (int j = 0; j < 4; ++j) v[j] = silu_scaled(v[j]);
                 }
                 if (RES) {
                     const h4 r = *reinterpret_cast<const h4*>(res + (size_t)row[i] * N + c);
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+                for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
 #pragma unroll 1
             for (int ky = 0; ky < KS; ++ky) {
                 const int iy = oy * ST - pad_t + ky;
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
                 h8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float y = silu_f(acc[t][j] + bs[j]);
+                    const float y = silu_scaled(acc[t][j]);
                     pooled[j] += y;
                     o[j] = (_Float16)y;
                 }
@@ -683,8 +687,9 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     const int P = (wy1 - wy0) * ww;
     const int ES = CC * 2 + 16;  // bytes per E row
     const int NTC = CC >> 4;
-    float* wl = reinterpret_cast<float*>(smem + wl_off);    // [KS*KS][CC] depthwise taps of this chunk
-    float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]
+    float* wl = reinterpret_cast<float*>(smem + wl_off);    // [KS*KS][CC] depthwise taps of this chunk, then bias [CC]
+    float* bl = wl + KS * KS * CC;                          // expand bias of this chunk
+    float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]; aliases E (used after phase 2)
     // ---------------- phase 0: issue every global load this workgroup needs ----------------
     int p[NPAIR][2];
     h8 xf[NPAIR][2][KSTEPS];
@@ -708,10 +713,11 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
         const int tap = i / CC, c = i - tap * CC;
         wl[i] = Wdw[(size_t)tap * Ce + chunk * CC + c];
     }
+    if (tid < CC) bl[tid] = bexp[chunk * CC + tid];
+    __syncthreads();
     // ---------------- phase 1: expand GEMM into LDS ----------------
     {
         const _Float16* wbase = Wexp + ((size_t)chunk * CC + m) * Kp + q * 8;
-        const float* bb = bexp + chunk * CC + 4 * q;
         h8 wn[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) wn[ks] = *reinterpret_cast<const h8*>(wbase + ks * 32);
@@ -724,11 +730,11 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 for (int ks = 0; ks < KSTEPS; ++ks)
                     wn[ks] = *reinterpret_cast<const h8*>(wbase + (size_t)(t + 1) * 16 * Kp + ks * 32);
             }
-            const f4 bv = *reinterpret_cast<const f4*>(bb + t * 16);
+            const f4 bv = *reinterpret_cast<const f4*>(bl + t * 16 + 4 * q);  // bias = accumulator init
 #pragma unroll
             for (int pr = 0; pr < NPAIR; ++pr) {
                 if (((pr * 4 + wave) * 2) * 16 >= P) continue;  // wave-uniform: no position in this pair
-                f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+                f4 a0 = bv, a1 = bv;
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) {
                     a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xf[pr][0][ks], a0, 0, 0, 0);
@@ -737,8 +743,8 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 h4 o0, o1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o0[j] = (_Float16)silu_f(a0[j] + bv[j]);
-                    o1[j] = (_Float16)silu_f(a1[j] + bv[j]);
+                    o0[j] = (_Float16)silu_scaled(a0[j]);
+                    o1[j] = (_Float16)silu_scaled(a1[j]);
                 }
                 if (p[pr][0] < P) *reinterpret_cast<h4*>(smem + p[pr][0] * ES + (t * 16 + 4 * q) * 2) = o0;
                 if (p[pr][1] < P) *reinterpret_cast<h4*>(smem + p[pr][1] * ES + (t * 16 + 4 * q) * 2) = o1;
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+                for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
 #pragma unroll 1
             for (int ky = 0; ky < KS; ++ky) {
                 const int iy = oy * ST - pad + ky;
@@ -812,13 +818,16 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 h8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float y = silu_f(acc[t][j] + bs[j]);
+                    const float y = silu_scaled(acc[t][j]);
                     pooled[j] += y;
                     o[j] = (_Float16)y;
                 }
                 *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox + t) * Ce) = o;
             }
         }
+    }
+    __syncthreads();  // every wave is done reading E: its space is reused for the pool scratch
+    if (active) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[s * CC + cg * 8 + j] = pooled[j];
     }

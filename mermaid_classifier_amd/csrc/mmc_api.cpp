@@ -57,6 +57,10 @@ static const BlockDef B0_BLOCKS[16] = {
     {5, 1, 6, 80, 112}, {5, 1, 6, 112, 112}, {5, 1, 6, 112, 112}, {5, 2, 6, 112, 192},
     {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {3, 1, 6, 192, 320}};
 static const int STEM_CH = 32, HEAD_IN = 320, FEAT = 1280, IMG = 224;
+// Scaled activation domain (kernels.hip, silu_scaled): every SiLU output is stored times log2(e).
+// Producers (stem, expand, depthwise, head) get weights/bias times LOG2E, consumers times 1/LOG2E;
+// for the depthwise taps the two cancel, so only its bias is scaled.
+static const double LOG2E = 1.4426950408889634;
 
 static void same_pad(int size, int k, int s, int* before, int* out)
 {
@@ -193,7 +197,8 @@ static int dev_upload(mmc_backbone* bb, T** p, const std::vector<T>& host)
 // fragment (chunk, kstep, t) = 1 KB at ((chunk*KS32 + kstep)*nt + t)*512 halves; inside it lane
 // (q*16 + m) holds W[channel(chunk, t, m)][kstep*32 + q*8 .. +8], with the row permutation
 // fragment row (t*16 + 4qr + jr) <- channel (chunk*16nt + qr*4nt + 4t + jr).
-static int pack_pw(mmc_backbone* bb, PwLayer* L, const float* w, const float* b, int N, int K, int force_nt)
+static int pack_pw(mmc_backbone* bb, PwLayer* L, const float* w, const float* b, int N, int K, int force_nt,
+                   double wscale, double bscale)
 {
     L->N = N;
     L->K = K;
@@ -216,10 +221,10 @@ static int pack_pw(mmc_backbone* bb, PwLayer* L, const float* w, const float* b,
                             const int k = ks * 32 + q * 8 + j;
                             if (k >= K) continue;
                             const size_t off = ((((size_t)ch * ks32 + ks) * L->nt + t) * 64 + (q * 16 + m)) * 8 + j;
-                            wp[off] = (_Float16)w[(size_t)c * K + k];
+                            wp[off] = (_Float16)(float)(w[(size_t)c * K + k] * wscale);
                         }
                 }
-    for (int c = 0; c < N; ++c) bp[c] = b[c];
+    for (int c = 0; c < N; ++c) bp[c] = (float)(b[c] * bscale);
     int r = dev_upload(bb, &L->w, wp);
     if (r) return r;
     return dev_upload(bb, &L->b, bp);
@@ -284,11 +289,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     const int c = q * 8 + 4 * t + j;
                     const float* wc = w + (size_t)c * 27;
                     for (int qq = 0; qq < 3; ++qq)           // kernel row qq, bytes 0..7 of its 9-byte run
-                        for (int jj = 0; jj < 8; ++jj) wp[prow * 32 + qq * 8 + jj] = (_Float16)wc[qq * 9 + jj];
-                    for (int jj = 0; jj < 3; ++jj) wp[prow * 32 + 24 + jj] = (_Float16)wc[jj * 9 + 8];
+                        for (int jj = 0; jj < 8; ++jj) wp[prow * 32 + qq * 8 + jj] = (_Float16)(float)(wc[qq * 9 + jj] * LOG2E);
+                    for (int jj = 0; jj < 3; ++jj) wp[prow * 32 + 24 + jj] = (_Float16)(float)(wc[jj * 9 + 8] * LOG2E);
                 }
         TRY_OR_FREE(dev_upload(bb, &bb->stem_w, wp));
-        TRY_OR_FREE(dev_upload(bb, &bb->stem_b, std::vector<float>(b, b + STEM_CH)));
+        std::vector<float> sb(STEM_CH);
+        for (int c = 0; c < STEM_CH; ++c) sb[c] = (float)(b[c] * LOG2E);
+        TRY_OR_FREE(dev_upload(bb, &bb->stem_b, sb));
         std::vector<float> pvv = {pv[0], pv[1], pv[2], 0.f};
         TRY_OR_FREE(dev_upload(bb, &bb->stem_pad, pvv));
     }
@@ -313,7 +320,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             snprintf(nm, sizeof nm, "b%d.expand", i);
             TAKE(w, (size_t)B.ce * B.d.cin, nm);
             TAKE(b, B.ce, nm);
-            TRY_OR_FREE(pack_pw(bb, &B.expand, w, b, B.ce, B.d.cin, 0));
+            TRY_OR_FREE(pack_pw(bb, &B.expand, w, b, B.ce, B.d.cin, 0, LOG2E, LOG2E));
             exp_w_host = w;
         }
         {
@@ -325,7 +332,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             for (int c = 0; c < B.ce; ++c)
                 for (int t = 0; t < kk; ++t) wt[(size_t)t * B.ce + c] = w[(size_t)c * kk + t];
             TRY_OR_FREE(dev_upload(bb, &B.dw_w, wt));
-            TRY_OR_FREE(dev_upload(bb, &B.dw_b, std::vector<float>(b, b + B.ce)));
+            std::vector<float> db(B.ce);
+            for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
+            TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
         }
         {
             snprintf(nm, sizeof nm, "b%d.se", i);
@@ -333,7 +342,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(br, B.cs, nm);
             TAKE(we, (size_t)B.ce * B.cs, nm);
             TAKE(be, B.ce, nm);
-            TRY_OR_FREE(dev_upload(bb, &B.se_wr, std::vector<float>(wr, wr + (size_t)B.cs * B.ce)));
+            std::vector<float> wrs((size_t)B.cs * B.ce);   // pooled sums are of log2(e)-scaled activations
+            for (size_t e = 0; e < wrs.size(); ++e) wrs[e] = (float)(wr[e] / LOG2E);
+            TRY_OR_FREE(dev_upload(bb, &B.se_wr, wrs));
             TRY_OR_FREE(dev_upload(bb, &B.se_br, std::vector<float>(br, br + B.cs)));
             std::vector<float> weT((size_t)B.cs * B.ce);   // [Cs][Ce]: coalesced reads in se_gate_kernel
             for (int c = 0; c < B.ce; ++c)
@@ -345,7 +356,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             snprintf(nm, sizeof nm, "b%d.project", i);
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
-            TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0));
+            TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
         }
         // depthwise geometry
         B.tw = (B.Ho % 4 == 0) ? 4 : (B.Ho % 7 == 0 && B.Ho <= 7 ? 7 : 2);
@@ -377,13 +388,14 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 const int ppad = (wh * wwid + 15) / 16 * 16;
                 B.f_npair = (ppad / 16 + 7) / 8;
                 B.f_wl_off = ppad * (fc.CC * 2 + 16);
-                B.f_red_off = B.f_wl_off + B.d.k * B.d.k * fc.CC * 4;
-                B.f_lds = B.f_red_off + B.f_S * fc.CC * 4;
+                B.f_red_off = 0;  // pool scratch aliases E (S*CC*4 = 8 KB <= E)
+                B.f_lds = B.f_wl_off + (B.d.k * B.d.k + 1) * fc.CC * 4;
+                if (B.f_S * fc.CC * 4 > B.f_wl_off) B.f_lds = 1 << 30;
                 const int kp = 32 * B.f_ksteps;
                 if (B.f_lds <= 64 * 1024 && fc.TWo % B.f_tw == 0) {
                     std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
                     for (int c = 0; c < B.ce; ++c)
-                        for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)exp_w_host[(size_t)c * B.d.cin + k];
+                        for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)(float)(exp_w_host[(size_t)c * B.d.cin + k] * LOG2E);
                     TRY_OR_FREE(dev_upload(bb, &B.exp_nat, wn));
                     B.fused = true;
                     const size_t pp = (size_t)B.f_tiles_x * B.f_tiles_y * B.ce;
@@ -401,7 +413,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     {
         TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
         TAKE(b, FEAT, "head.bias");
-        TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4));
+        TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -465,7 +477,7 @@ static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int
     GemmArgs a{};
     a.X = X; a.M = M; a.K = L.K; a.Wp = L.w; a.Kp = L.Kp; a.bias = L.b; a.Y = Y; a.N = L.N;
     a.nt = L.nt; a.n_chunks = L.n_chunks; a.epi = epi; a.gate = gate; a.HW = HW; a.res = res;
-    a.gap_out = gap_out; a.inv_hw = 1.0f / (float)HW;
+    a.gap_out = gap_out; a.inv_hw = (float)(1.0 / ((double)HW * LOG2E));  // GAP input is log2(e)-scaled
     a.mt = gemm_mt(L, M);
     return launch_pw_gemm(a, st);
 }
@@ -589,7 +601,11 @@ extern "C" int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, 
     if (s.is_half) {
         std::vector<_Float16> tmp(s.elems);
         HIP_TRY(hipMemcpy(tmp.data(), s.dev, s.elems * 2, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < s.elems; ++i) out[i] = (float)tmp[i];
+        const size_t ln = strlen(name);
+        const bool scaled = strcmp(name, "stem") == 0 || (ln > 3 && strcmp(name + ln - 3, ".dw") == 0) ||
+                            (ln > 7 && strcmp(name + ln - 7, ".expand") == 0);   // SiLU outputs live times log2(e)
+        const float inv = scaled ? (float)(1.0 / LOG2E) : 1.0f;
+        for (size_t i = 0; i < s.elems; ++i) out[i] = (float)tmp[i] * inv;
     } else {
         HIP_TRY(hipMemcpy(out, s.dev, s.elems * 4, hipMemcpyDeviceToHost));
     }
