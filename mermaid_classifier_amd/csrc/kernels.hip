@@ -657,7 +657,10 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
 //            thread) and accumulates in fp32 with v_fma_mix_f32; image borders are handled by tap
 //            predication (padding is zero in the expanded domain, so skipped taps are exact).
 // ---------------------------------------------------------------------------------------------
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR>
+// CC (channels per chunk) and TWO (output tile width) are template parameters so that every row
+// stride, channel-group split and strip decode is constant arithmetic: the kernel is VALU-bound and
+// runtime integer multiplies/divides were ~half of its instruction stream.
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO>
 __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
                                                        const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
                                                        const float* __restrict__ bexp,     // [Ce]
@@ -666,11 +669,13 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                                                        _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
                                                        float* __restrict__ pool_part,      // [B][ntiles][Ce]
                                                        int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
-                                                       int TWo, int tiles_x, int CC, int CCG, int S, int wl_off,
-                                                       int red_off)
+                                                       int tiles_x, int wl_off, int red_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Kp = 32 * KSTEPS;
+    constexpr int TWo = TWO, CCG = CC / 8, S = 256 / CCG;
+    constexpr int ES = CC * 2 + 16;  // bytes per E row
+    constexpr int NTC = CC / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
@@ -685,8 +690,7 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     wx1 = wx1 > W ? W : wx1;
     const int ww = wx1 - wx0;
     const int P = (wy1 - wy0) * ww;
-    const int ES = CC * 2 + 16;  // bytes per E row
-    const int NTC = CC >> 4;
+    const unsigned wmagic = (65536u + ww - 1) / ww;  // p / ww == (p * wmagic) >> 16 for p < 65536 / ww
     float* wl = reinterpret_cast<float*>(smem + wl_off);    // [KS*KS][CC] depthwise taps of this chunk, then bias [CC]
     float* bl = wl + KS * KS * CC;                          // expand bias of this chunk
     float* red = reinterpret_cast<float*>(smem + red_off);  // [S][CC]; aliases E (used after phase 2)
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
             const int pp = ((pr * 4 + wave) * 2 + i) * 16 + m;
             p[pr][i] = pp;
             const bool ok = pp < P;
-            const int py = ok ? pp / ww : 0, px = ok ? pp - py * ww : 0;
+            const int py = ok ? (int)(((unsigned)pp * wmagic) >> 16) : 0, px = ok ? pp - py * ww : 0;
             const _Float16* xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     const bool active = tid < CCG * S;
     const int cg = tid % CCG, s = tid / CCG;
     const int cglob = chunk * CC + cg * 8;
-    const int spr = TWo / TW;
+    constexpr int spr = TWo / TW;
     const int nstrips = TH * spr;
     float pooled[8];
 #pragma unroll
@@ -990,33 +994,34 @@ int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int 
     return 0;
 }
 
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR>
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO>
 static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
 {
     dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, a.B);
-    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp,
-                       a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH, a.TWo,
-                       a.tiles_x, a.CC, a.CCG, a.S, a.wl_off, a.red_off);
+    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO>), grid, dim3(256), a.lds_bytes, st, a.X,
+                       a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH,
+                       a.tiles_x, a.wl_off, a.red_off);
     LAUNCH_CHECK();
     return 0;
 }
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st)
 {
-#define MB_CASE(KS, ST, TW, KSTEPS, NPAIR)                                                          \
-    if (a.ks == KS && a.stride == ST && a.tw == TW && a.ksteps == KSTEPS && a.npair == NPAIR)       \
-        return launch_mbconv_t<KS, ST, TW, KSTEPS, NPAIR>(a, st);
-    MB_CASE(3, 2, 2, 1, 3)
-    MB_CASE(3, 1, 2, 1, 2)
-    MB_CASE(5, 2, 2, 1, 3)
-    MB_CASE(5, 1, 2, 2, 3)
-    MB_CASE(3, 2, 2, 2, 2)
-    MB_CASE(3, 1, 2, 3, 2)
-    MB_CASE(5, 1, 2, 3, 2)
-    MB_CASE(5, 1, 2, 4, 2)
-    MB_CASE(5, 2, 1, 4, 2)
-    MB_CASE(5, 1, 1, 6, 1)
-    MB_CASE(3, 1, 1, 6, 1)
+#define MB_CASE(KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_)                                                   \
+    if (a.ks == KS_ && a.stride == ST_ && a.tw == TW_ && a.ksteps == KSTEPS_ && a.npair == NPAIR_ &&         \
+        a.CC == CC_ && a.TWo == TWO_)                                                                        \
+        return launch_mbconv_t<KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_>(a, st);
+    MB_CASE(3, 2, 2, 1, 3, 48, 8)     // b1
+    MB_CASE(3, 1, 2, 1, 2, 48, 14)    // b2
+    MB_CASE(5, 2, 2, 1, 3, 48, 14)    // b3
+    MB_CASE(5, 1, 2, 2, 3, 48, 14)    // b4
+    MB_CASE(3, 2, 2, 2, 2, 80, 14)    // b5
+    MB_CASE(3, 1, 2, 3, 2, 96, 14)    // b6, b7
+    MB_CASE(5, 1, 2, 3, 2, 96, 14)    // b8
+    MB_CASE(5, 1, 2, 4, 2, 96, 14)    // b9, b10
+    MB_CASE(5, 2, 1, 4, 2, 96, 7)     // b11
+    MB_CASE(5, 1, 1, 6, 1, 192, 7)    // b12-b14
+    MB_CASE(3, 1, 1, 6, 1, 192, 7)    // b15
 #undef MB_CASE
     return -5;
 }
