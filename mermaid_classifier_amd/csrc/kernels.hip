@@ -407,80 +407,98 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Squeeze-excite gate in two launches (both latency-bound, so both spread over many waves):
-// se_reduce_kernel: one workgroup per patch; se_expand_kernel: one thread per (patch, channel).
+// Squeeze-excite gate in two launches:
 //   pooled[c] = inv_hw * sum_p pool_part[b][p][c]
 //   r[j]      = silu(b_r[j] + sum_c W_r[j][c] pooled[c])        j < Cs   (wave-reduced dot products)
 //   gate[c]   = sigmoid(b_e[c] + sum_j W_e[c][j] r[j])      (W_e stored transposed, [Cs][C])
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
-                                                        float inv_hw, const float* __restrict__ Wr,
-                                                        const float* __restrict__ br, float* __restrict__ rout)
+// Both squeeze-excite FCs are batch GEMMs over the patches, run on the exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32) so that a weight row is fetched once per 16 patches, not once per patch.
+//   XMODE 1: X[row][k] = sum_{p<nslab} Xs[(row*nslab + p)*K + k]        (pool partial sums of a patch)
+//   XMODE 2: X[row][k] = silu(xbias[k] + sum_{z<nslab} Xs[(z*M + row)*K + k])   (split-K partials of FC1)
+//   ACT 0: Y slab z = partial products over this z's K range (no bias)   ACT 2: sigmoid(acc + bias)
+// Lane (i=l&15, q=l>>4) feeds 4 consecutive k per 16-k group (one per MFMA step); outputs land as
+// lane (i,q) -> columns n0 + 16t + 4q + j of row i (operands swapped, as in the other GEMMs).
+template <int XMODE, int ACT>
+__global__ __launch_bounds__(256) void se_gemm_f32_kernel(const float* __restrict__ Xs, int nslab, int M, int K,
+                                                          const float* __restrict__ xbias,
+                                                          const float* __restrict__ W,   // [N][K]
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          int N, int kz)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled[C]
-    float* pooled = sm;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* pp = pool_part + (size_t)b * nparts * C;
-    for (int c = tid; c < C; c += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int p = 0;
-        for (; p + 3 < nparts; p += 4) {
-            s0 += pp[(size_t)p * C + c];
-            s1 += pp[(size_t)(p + 1) * C + c];
-            s2 += pp[(size_t)(p + 2) * C + c];
-            s3 += pp[(size_t)(p + 3) * C + c];
-        }
-        for (; p < nparts; ++p) s0 += pp[(size_t)p * C + c];
-        pooled[c] = ((s0 + s1) + (s2 + s3)) * inv_hw;
-    }
-    __syncthreads();
-    // wave w owns outputs j = w, w+4, ...; lanes stride over C with 16-byte loads; 4 outputs in flight
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int j0 = wave; j0 < Cs; j0 += 16) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane * 4; c < C; c += 256) {
-            const f4 x = *reinterpret_cast<const f4*>(pooled + c);
+    constexpr int NT = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + i;
+    const bool rok = row < M;
+    const int n0 = blockIdx.y * 16 * NT;
+    const int kbeg = blockIdx.z * kz;
+    const int kend = (kbeg + kz) < K ? (kbeg + kz) : K;
+    f4 acc[NT][2];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + 4 * u;
-                if (j < Cs) {
-                    const f4 w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + c);
-                    s[u] += (w[0] * x[0] + w[1] * x[1]) + (w[2] * x[2] + w[3] * x[3]);
+    for (int t = 0; t < NT; ++t) acc[t][0] = acc[t][1] = (f4){0.f, 0.f, 0.f, 0.f};
+    // U k-groups per batch: every load of a batch is issued before its MFMAs (these GEMMs are pure
+    // latency chains: tiny, with all operands a fresh L2/HBM round trip away)
+    constexpr int U = 3;
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * U) {
+        f4 xv[U], wv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 16 * u + 4 * q;
+            const bool kok = k < kend;
+            f4 x = {0.f, 0.f, 0.f, 0.f};
+            if (rok && kok) {
+                if (XMODE == 1) {
+                    const float* xp = Xs + (size_t)row * nslab * K + k;
+                    f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s0, s3 = s0;
+                    int p = 0;
+                    for (; p + 3 < nslab; p += 4) {
+                        s0 += *reinterpret_cast<const f4*>(xp + (size_t)p * K);
+                        s1 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 1) * K);
+                        s2 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 2) * K);
+                        s3 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 3) * K);
+                    }
+                    for (; p < nslab; ++p) s0 += *reinterpret_cast<const f4*>(xp + (size_t)p * K);
+                    x = (s0 + s1) + (s2 + s3);
+                } else {
+                    f4 sum = *reinterpret_cast<const f4*>(xbias + k);
+#pragma unroll 8
+                    for (int z = 0; z < nslab; ++z)
+                        sum += *reinterpret_cast<const f4*>(Xs + ((size_t)z * M + row) * K + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = silu_f(sum[j]);
                 }
+            }
+            xv[u] = x;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + i;
+                f4 w = {0.f, 0.f, 0.f, 0.f};
+                if (n < N && kok) w = *reinterpret_cast<const f4*>(W + (size_t)n * K + k);
+                wv[u][t] = w;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float v = s[u];
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            const int j = j0 + 4 * u;
-            if (lane == 0 && j < Cs) rout[(size_t)b * Cs + j] = silu_f(v + br[j]);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t][s], xv[u][s], acc[t][s & 1], 0, 0, 0);
+    }
+    if (!rok) return;
+    float* yo = Y + (ACT == 0 ? (size_t)blockIdx.z * M * N : 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + t * 16 + 4 * q + j;
+            if (n < N) {
+                float v = acc[t][0][j] + acc[t][1][j];
+                if (ACT == 2) v = sigmoid_f(v + bias[n]);
+                yo[(size_t)row * N + n] = v;
+            }
         }
-    }
-}
-
-// gate[b][c] = sigmoid(be[c] + sum_j WeT[j][c] r[b][j]);  grid (C/256, B); WeT is [Cs][C] (coalesced)
-__global__ __launch_bounds__(256) void se_expand_kernel(const float* __restrict__ r, int C, int Cs,
-                                                        const float* __restrict__ WeT, const float* __restrict__ be,
-                                                        float* __restrict__ gate)
-{
-    __shared__ float rs[64];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    if (tid < Cs) rs[tid] = r[(size_t)b * Cs + tid];
-    __syncthreads();
-    const int c = blockIdx.x * 256 + tid;
-    if (c >= C) return;
-    float s0 = be[c], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int j = 0;
-    for (; j + 3 < Cs; j += 4) {
-        s0 += WeT[(size_t)j * C + c] * rs[j];
-        s1 += WeT[(size_t)(j + 1) * C + c] * rs[j + 1];
-        s2 += WeT[(size_t)(j + 2) * C + c] * rs[j + 2];
-        s3 += WeT[(size_t)(j + 3) * C + c] * rs[j + 3];
-    }
-    for (; j < Cs; ++j) s0 += WeT[(size_t)j * C + c] * rs[j];
-    gate[(size_t)b * C + c] = sigmoid_f((s0 + s1) + (s2 + s3));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -953,14 +971,19 @@ int launch_dwconv(const DwArgs& a, hipStream_t st)
     return -4;
 }
 
-int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs, float inv_hw, const float* Wr,
-                   const float* br, const float* WeT, const float* be, float* rbuf, float* gate, hipStream_t st)
+int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* Wr, const float* br,
+                   const float* We, const float* be, float* rpart, int kz_slabs, float* gate, hipStream_t st)
 {
-    if (Cs > 64) return -6;
-    hipLaunchKernelGGL(se_reduce_kernel, dim3(B), dim3(256), (size_t)C * sizeof(float), st, pool_part, nparts, C, Cs,
-                       inv_hw, Wr, br, rbuf);
+    // FC1 (reduce): [B x C] x [C x Cs4], split over K into kz_slabs partial slabs
+    const int kz = ((C + kz_slabs - 1) / kz_slabs + 15) / 16 * 16;
+    const int nz = (C + kz - 1) / kz;
+    dim3 g1((B + 63) / 64, (Cs4 + 63) / 64, nz);
+    hipLaunchKernelGGL((se_gemm_f32_kernel<1, 0>), g1, dim3(256), 0, st, pool_part, nparts, B, C, nullptr, Wr, nullptr,
+                       rpart, Cs4, kz);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(se_expand_kernel, dim3((C + 255) / 256, B), dim3(256), 0, st, rbuf, C, Cs, WeT, be, gate);
+    // FC2 (expand): silu(br + sum of slabs) [B x Cs4] x [Cs4 x C] -> sigmoid -> gate
+    dim3 g2((B + 63) / 64, (C + 63) / 64, 1);
+    hipLaunchKernelGGL((se_gemm_f32_kernel<2, 2>), g2, dim3(256), 0, st, rpart, nz, B, Cs4, br, We, be, gate, C, Cs4);
     LAUNCH_CHECK();
     return 0;
 }

@@ -98,7 +98,7 @@ static int pick_nt(int N, bool small_m)
 
 struct BlockW {
     BlockDef d;
-    int H = 0, Ho = 0, ce = 0, cs = 0, pad = 0;
+    int H = 0, Ho = 0, ce = 0, cs = 0, cs4 = 0, pad = 0;
     bool has_expand = false, skip = false;
     PwLayer expand, project;
     float *dw_w = nullptr, *dw_b = nullptr;                    // [k*k][ce], [ce]
@@ -342,14 +342,21 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(br, B.cs, nm);
             TAKE(we, (size_t)B.ce * B.cs, nm);
             TAKE(be, B.ce, nm);
-            std::vector<float> wrs((size_t)B.cs * B.ce);   // pooled sums are of log2(e)-scaled activations
-            for (size_t e = 0; e < wrs.size(); ++e) wrs[e] = (float)(wr[e] / LOG2E);
+            // FC1 weights [cs4][ce]: rows padded to a multiple of 4 outputs (zero rows -> silu(0) = 0), scaled by
+            // 1/(HW*log2e): the pooled sums are over HW pixels of log2(e)-scaled activations.
+            B.cs4 = (B.cs + 3) / 4 * 4;
+            const double psc = 1.0 / ((double)B.Ho * B.Ho * LOG2E);
+            std::vector<float> wrs((size_t)B.cs4 * B.ce, 0.f), brs(B.cs4, 0.f);
+            for (int j = 0; j < B.cs; ++j) {
+                for (int c = 0; c < B.ce; ++c) wrs[(size_t)j * B.ce + c] = (float)(wr[(size_t)j * B.ce + c] * psc);
+                brs[j] = br[j];
+            }
             TRY_OR_FREE(dev_upload(bb, &B.se_wr, wrs));
-            TRY_OR_FREE(dev_upload(bb, &B.se_br, std::vector<float>(br, br + B.cs)));
-            std::vector<float> weT((size_t)B.cs * B.ce);   // [Cs][Ce]: coalesced reads in se_gate_kernel
+            TRY_OR_FREE(dev_upload(bb, &B.se_br, brs));
+            std::vector<float> wes((size_t)B.ce * B.cs4, 0.f);   // FC2 weights [ce][cs4], zero-padded columns
             for (int c = 0; c < B.ce; ++c)
-                for (int j = 0; j < B.cs; ++j) weT[(size_t)j * B.ce + c] = we[(size_t)c * B.cs + j];
-            TRY_OR_FREE(dev_upload(bb, &B.se_we, weT));
+                for (int j = 0; j < B.cs; ++j) wes[(size_t)c * B.cs4 + j] = we[(size_t)c * B.cs + j];
+            TRY_OR_FREE(dev_upload(bb, &B.se_we, wes));
             TRY_OR_FREE(dev_upload(bb, &B.se_be, std::vector<float>(be, be + B.ce)));
         }
         {
@@ -426,7 +433,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     TRY_OR_FREE(dev_alloc(bb, &bb->dwbuf, mb * max_dw));
     TRY_OR_FREE(dev_alloc(bb, &bb->pool_part, mb * max_pool));
     TRY_OR_FREE(dev_alloc(bb, &bb->gate, mb * (size_t)max_c));
-    TRY_OR_FREE(dev_alloc(bb, &bb->se_r, mb * (size_t)64));
+    TRY_OR_FREE(dev_alloc(bb, &bb->se_r, mb * (size_t)48 * 24));   // up to 24 split-K slabs of [n][cs4<=48]
     TRY_OR_FREE(dev_alloc(bb, &bb->in_stage, mb * (size_t)IMG * IMG * 3));
     TRY_OR_FREE(dev_alloc(bb, &bb->out_stage, mb * (size_t)FEAT));
 #undef TAKE
@@ -542,8 +549,8 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         snprintf(nm, sizeof nm, "b%d.dw", i);
         if (bb->keep) { int r = save_act(bb, nm, bb->dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        STEP(nm, "se_gate", launch_se_gate(bb->pool_part, nparts, n, B.ce, B.cs, 1.0f / (float)HWo, B.se_wr, B.se_br, B.se_we,
-                                B.se_be, bb->se_r, bb->gate, st));
+        STEP(nm, "se_gate", launch_se_gate(bb->pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
+                                           bb->se_r, (B.ce + 47) / 48 > 24 ? 24 : (B.ce + 47) / 48, bb->gate, st));
         if (bb->keep) { int r = save_act(bb, nm, bb->gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
