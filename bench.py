@@ -146,7 +146,8 @@ def main():
         value = world * BATCH * args.steps / elapsed
         # per-kernel durations, HIP events on the launch stream, same resident workload
         per_kernel = defaultdict(lambda: [0.0, 0, 0])  # ms, launches, bytes
-        alg = {l.name: l for l in schedule.b0_launches(BATCH)}
+        sub = -(-BATCH // bb.lanes)   # each launch of the schedule covers one lane's sub-batch
+        alg = {l.name: l for l in schedule.b0_launches(sub)}
         launched = []
         for _ in range(args.profile_passes):
             for name, ms in bb.profile(patches, feats):
@@ -162,6 +163,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": schedule.HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / schedule.HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
+                    "patches_per_launch": sub,
                     "alg_bytes_per_launch": nbytes / launches,
                     "whole_net": {"alg_GB_per_step": tot["bytes"] / 1e9,
                                   "hbm_frac_at_value": tot["bytes_per_patch"] * value / 1e9 / schedule.HBM_PEAK_GBS,
@@ -174,6 +176,7 @@ def main():
             "config": {"workload": "EfficientNet-B0 forward, batch=256 random 224x224 u8 patches per GPU -> (256,1280) fp32"
                                    + ("; RCCL all-gather of features" if world > 1 else ""),
                        "per_gpu_batch": BATCH, "global_batch": world * BATCH, "weights": "synthetic seed 0",
+                       "lanes_per_gpu": bb.lanes,
                        "parallelism": f"patch-sharded x{world}"},
             "roofline": roofline,
         }

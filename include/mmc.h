@@ -65,6 +65,9 @@ int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device,
 void mmc_backbone_destroy(mmc_backbone* bb);
 int mmc_feature_dim(const mmc_backbone* bb);            /* 1280 for B0 */
 int mmc_backbone_max_batch(const mmc_backbone* bb);
+/* A pass is split into this many sub-batches that run concurrently on internal HIP streams (forked from and
+ * joined to `hip_stream`); env MMC_LANES overrides the default of 2.  Results do not depend on it. */
+int mmc_backbone_lanes(const mmc_backbone* bb);
 size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb);
 
 /* patches: n x 224 x 224 x 3 u8 (HWC, RGB).  out_features: n x feature_dim fp32, row i = patch i.
@@ -83,6 +86,8 @@ int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, float* out,
 
 /* Kernel timing hook for bench.py: runs `iters` passes over `n` resident patches and returns the
  * HIP-event elapsed milliseconds of every launch ("<layer>|<kernel instantiation>"), measured on `hip_stream`.
+ * Sub-batches (see mmc_backbone_lanes) are run one after the other here, so each layer appears once per lane
+ * with ceil(n / lanes) patches.
  * names/ms arrays have `cap` slots; *n_out receives the number filled. */
 int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, float* out_features_dev,
                          void* hip_stream, char (*names)[64], float* ms, int* launches, int cap, int* n_out);

@@ -18,7 +18,7 @@ MMC_IN_HOST, MMC_OUT_HOST = 1, 2
 # every symbol include/mmc.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "mmc_last_error", "mmc_version", "mmc_device_count",
-    "mmc_backbone_create", "mmc_backbone_destroy", "mmc_feature_dim", "mmc_backbone_max_batch",
+    "mmc_backbone_create", "mmc_backbone_destroy", "mmc_feature_dim", "mmc_backbone_max_batch", "mmc_backbone_lanes",
     "mmc_backbone_workspace_bytes", "mmc_backbone_extract", "mmc_backbone_read_activation",
     "mmc_backbone_profile", "mmc_crop_patches",
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
@@ -50,6 +50,8 @@ def _load() -> C.CDLL:
     lib.mmc_feature_dim.argtypes = [vp]
     lib.mmc_backbone_max_batch.restype = i32
     lib.mmc_backbone_max_batch.argtypes = [vp]
+    lib.mmc_backbone_lanes.restype = i32
+    lib.mmc_backbone_lanes.argtypes = [vp]
     lib.mmc_backbone_workspace_bytes.restype = sz
     lib.mmc_backbone_workspace_bytes.argtypes = [vp]
     lib.mmc_backbone_extract.restype = i32

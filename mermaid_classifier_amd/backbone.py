@@ -71,6 +71,7 @@ class Backbone:
                                            int(max_batch), C.byref(self._h)))
         self.max_batch = int(max_batch)
         self.feature_dim = lib.mmc_feature_dim(self._h)
+        self.lanes = lib.mmc_backbone_lanes(self._h)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -134,9 +134,18 @@ struct mmc_backbone {
     float *stem_b = nullptr, *stem_pad = nullptr;
     BlockW blk[16];
     PwLayer head;
-    // workspace
-    _Float16 *act0 = nullptr, *act1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
-    float *pool_part = nullptr, *gate = nullptr, *se_r = nullptr;
+    // workspace: one lane per internal stream.  A pass over n patches is split into `nlanes` independent
+    // sub-batches that run concurrently on their own HIP streams, so the latency-bound small launches of
+    // one lane (squeeze-excite FCs, 7x7 layers) overlap the bandwidth/VALU-bound launches of the other.
+    struct Lane {
+        _Float16 *act0 = nullptr, *act1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
+        float *pool_part = nullptr, *gate = nullptr, *se_r = nullptr;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    Lane lanes[4];
+    int nlanes = 1, lane_cap = 0;
+    hipEvent_t fork = nullptr;
     uint8_t* in_stage = nullptr;
     float* out_stage = nullptr;
     size_t ws_bytes = 0;
@@ -236,6 +245,11 @@ extern "C" void mmc_backbone_destroy(mmc_backbone* bb)
     hipSetDevice(bb->device);
     for (void* p : bb->allocs) hipFree(p);
     for (auto& kv : bb->saved) hipFree(kv.second.dev);
+    for (int l = 0; l < 4; ++l) {
+        if (bb->lanes[l].stream) hipStreamDestroy(bb->lanes[l].stream);
+        if (bb->lanes[l].done) hipEventDestroy(bb->lanes[l].done);
+    }
+    if (bb->fork) hipEventDestroy(bb->fork);
     delete bb;
 }
 
@@ -427,13 +441,37 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         return fail(MMC_ERR_WEIGHTS, "weights blob has %u tensors, expected %u", nt, rd.next);
     }
     const size_t mb = (size_t)max_batch;
-    TRY_OR_FREE(dev_alloc(bb, &bb->act0, mb * max_act));
-    TRY_OR_FREE(dev_alloc(bb, &bb->act1, mb * max_act));
-    TRY_OR_FREE(dev_alloc(bb, &bb->expbuf, mb * (max_exp ? max_exp : 64)));
-    TRY_OR_FREE(dev_alloc(bb, &bb->dwbuf, mb * max_dw));
-    TRY_OR_FREE(dev_alloc(bb, &bb->pool_part, mb * max_pool));
-    TRY_OR_FREE(dev_alloc(bb, &bb->gate, mb * (size_t)max_c));
-    TRY_OR_FREE(dev_alloc(bb, &bb->se_r, mb * (size_t)48 * 24));   // up to 24 split-K slabs of [n][cs4<=48]
+    {
+        const char* ls = getenv("MMC_LANES");
+        int nl = ls ? atoi(ls) : 2;
+        if (nl < 1) nl = 1;
+        if (nl > 4) nl = 4;
+        if (bb->keep || max_batch < 2 * nl) nl = 1;
+        bb->nlanes = nl;
+        bb->lane_cap = (max_batch + nl - 1) / nl;
+        const size_t lc = (size_t)bb->lane_cap;
+        for (int l = 0; l < nl; ++l) {
+            mmc_backbone::Lane& L = bb->lanes[l];
+            TRY_OR_FREE(dev_alloc(bb, &L.act0, lc * max_act));
+            TRY_OR_FREE(dev_alloc(bb, &L.act1, lc * max_act));
+            TRY_OR_FREE(dev_alloc(bb, &L.expbuf, lc * (max_exp ? max_exp : 64)));
+            TRY_OR_FREE(dev_alloc(bb, &L.dwbuf, lc * max_dw));
+            TRY_OR_FREE(dev_alloc(bb, &L.pool_part, lc * max_pool));
+            TRY_OR_FREE(dev_alloc(bb, &L.gate, lc * (size_t)max_c));
+            TRY_OR_FREE(dev_alloc(bb, &L.se_r, lc * (size_t)48 * 24));   // up to 24 split-K slabs of [n][cs4<=48]
+            if (nl > 1) {
+                if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) {
+                    mmc_backbone_destroy(bb);
+                    return fail(MMC_ERR_HIP, "cannot create internal stream/event");
+                }
+            }
+        }
+        if (nl > 1 && hipEventCreateWithFlags(&bb->fork, hipEventDisableTiming) != hipSuccess) {
+            mmc_backbone_destroy(bb);
+            return fail(MMC_ERR_HIP, "cannot create fork event");
+        }
+    }
     TRY_OR_FREE(dev_alloc(bb, &bb->in_stage, mb * (size_t)IMG * IMG * 3));
     TRY_OR_FREE(dev_alloc(bb, &bb->out_stage, mb * (size_t)FEAT));
 #undef TAKE
@@ -444,6 +482,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
 
 extern "C" int mmc_feature_dim(const mmc_backbone* bb) { return bb ? FEAT : 0; }
 extern "C" int mmc_backbone_max_batch(const mmc_backbone* bb) { return bb ? bb->max_batch : 0; }
+extern "C" int mmc_backbone_lanes(const mmc_backbone* bb) { return bb ? bb->nlanes : 0; }
 extern "C" size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb) { return bb ? bb->ws_bytes : 0; }
 
 // ------------------------------------------------------------------------------------------
@@ -489,7 +528,8 @@ static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int
     return launch_pw_gemm(a, st);
 }
 
-static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
+static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t* patches_dev, int n, float* out_dev,
+                        hipStream_t st, Prof* prof)
 {
 #define STEP(nm, label, expr)                                                           \
     do {                                                                                \
@@ -507,8 +547,8 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         }                                                                               \
     } while (0)
     char nm[64];
-    _Float16* x = bb->act0;
-    _Float16* y = bb->act1;
+    _Float16* x = ws.act0;
+    _Float16* y = ws.act1;
     STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
     if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     for (int i = 0; i < 16; ++i) {
@@ -517,8 +557,8 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         int nparts = B.parts;
         if (B.fused) {
             MbArgs a{};
-            a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = bb->dwbuf;
-            a.pool_part = bb->pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
+            a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = ws.dwbuf;
+            a.pool_part = ws.pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
             a.Wo = B.Ho; a.pad = B.pad; a.ks = B.d.k; a.stride = B.d.s; a.tw = B.f_tw; a.ksteps = B.f_ksteps;
             a.TH = B.f_TH; a.TWo = B.f_TWo; a.tiles_x = B.f_tiles_x; a.tiles_y = B.f_tiles_y; a.CC = B.f_CC;
             a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair;
@@ -533,12 +573,12 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
             if (B.has_expand) {
                 snprintf(nm, sizeof nm, "b%d.expand", i);
                 STEP(nm, gemm_label(B.expand, n * HWi, EPI_SILU, false, false),
-                     run_gemm(B.expand, x, n * HWi, bb->expbuf, EPI_SILU, nullptr, HWi, nullptr, nullptr, st));
-                if (bb->keep) { int r = save_act(bb, nm, bb->expbuf, (size_t)n * HWi * B.ce, true, st); if (r) return r; }
-                dw_in = bb->expbuf;
+                     run_gemm(B.expand, x, n * HWi, ws.expbuf, EPI_SILU, nullptr, HWi, nullptr, nullptr, st));
+                if (bb->keep) { int r = save_act(bb, nm, ws.expbuf, (size_t)n * HWi * B.ce, true, st); if (r) return r; }
+                dw_in = ws.expbuf;
             }
             DwArgs d{};
-            d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = bb->dwbuf; d.pool_part = bb->pool_part;
+            d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = ws.dwbuf; d.pool_part = ws.pool_part;
             d.B = n; d.H = B.H; d.W = B.H; d.C = B.ce; d.Ho = B.Ho; d.Wo = B.Ho; d.pad_t = B.pad; d.pad_l = B.pad;
             d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts;
             snprintf(nm, sizeof nm, "b%d.dw", i);
@@ -547,13 +587,13 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
             STEP(nm, dl, launch_dwconv(d, st));
         }
         snprintf(nm, sizeof nm, "b%d.dw", i);
-        if (bb->keep) { int r = save_act(bb, nm, bb->dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
+        if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        STEP(nm, "se_gate", launch_se_gate(bb->pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
-                                           bb->se_r, (B.ce + 47) / 48 > 24 ? 24 : (B.ce + 47) / 48, bb->gate, st));
-        if (bb->keep) { int r = save_act(bb, nm, bb->gate, (size_t)n * B.ce, false, st); if (r) return r; }
+        STEP(nm, "se_gate", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
+                                           ws.se_r, (B.ce + 47) / 48 > 24 ? 24 : (B.ce + 47) / 48, ws.gate, st));
+        if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
-        STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, bb->dwbuf, n * HWo, y, EPI_LINEAR, bb->gate, HWo, B.skip ? x : nullptr, nullptr, st));
+        STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
         snprintf(nm, sizeof nm, "b%d.out", i);
         if (bb->keep) { int r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st); if (r) return r; }
         _Float16* t = x; x = y; y = t;
@@ -562,6 +602,36 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
     STEP("head", gemm_label(bb->head, n * HWh, EPI_GAP, false, false), run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
     bb->last_n = n;
 #undef STEP
+    return 0;
+}
+
+// One pass over n <= max_batch resident patches: split into lanes, fork from / join to the caller's stream.
+static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
+{
+    if (bb->nlanes == 1 || prof || n < 2 * bb->nlanes)
+        return (n <= bb->lane_cap) ? forward_lane(bb, bb->lanes[0], patches_dev, n, out_dev, st, prof)
+                                   : [&]() {
+                                         for (int off = 0; off < n; off += bb->lane_cap) {
+                                             const int cur = n - off < bb->lane_cap ? n - off : bb->lane_cap;
+                                             int r = forward_lane(bb, bb->lanes[0], patches_dev + (size_t)off * IMG * IMG * 3, cur,
+                                                                  out_dev + (size_t)off * FEAT, st, prof);
+                                             if (r) return r;
+                                         }
+                                         return 0;
+                                     }();
+    HIP_TRY(hipEventRecord(bb->fork, st));
+    const int per = (n + bb->nlanes - 1) / bb->nlanes;
+    for (int l = 0; l < bb->nlanes; ++l) {
+        const int off = l * per;
+        const int cur = n - off < per ? n - off : per;
+        if (cur <= 0) break;
+        mmc_backbone::Lane& L = bb->lanes[l];
+        HIP_TRY(hipStreamWaitEvent(L.stream, bb->fork, 0));
+        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * FEAT, L.stream, nullptr);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(L.done, L.stream));
+        HIP_TRY(hipStreamWaitEvent(st, L.done, 0));
+    }
     return 0;
 }
 
