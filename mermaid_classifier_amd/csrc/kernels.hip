@@ -502,6 +502,122 @@ __global__ __launch_bounds__(256) void se_gemm_f32_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Squeeze-excite in ONE launch: both FCs for 16 patches per workgroup of 16 waves.  The two tiny
+// GEMMs are pure latency chains, so the workgroup is wide instead of deep:
+//   FC1  r[16][Cs4] = silu(br + P[16][C] . Wr^T): the 16 waves split K (each sums its pool-partial slabs on
+//        the fly and issues all its loads before its exact-f32 MFMAs), partials meet in LDS;
+//   FC2  gate[16][C] = sigmoid(be + r . We^T): the 16 waves split the C/16 output fragments, r comes from LDS.
+// ---------------------------------------------------------------------------------------------
+#define SE_MAXG 5   // k-groups (16 k each) a wave may own in FC1: C <= 16 waves * 5 * 16 = 1280
+#define SE_MAXT 5   // output fragments a wave may own in FC2:     C <= 16 waves * 5 * 16 = 1280
+__global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict__ pool_part, int nslab, int M, int C,
+                                                        int Cs4, const float* __restrict__ Wr,  // [Cs4][C]
+                                                        const float* __restrict__ br,           // [Cs4]
+                                                        const float* __restrict__ We,           // [C][Cs4]
+                                                        const float* __restrict__ be, float* __restrict__ gate)
+{
+    __shared__ __attribute__((aligned(16))) float part[16][16][48];  // [wave][row][j]
+    __shared__ __attribute__((aligned(16))) float rs[16][48];        // [row][j]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + i;
+    const bool rok = row < M;
+    const int NJT = (Cs4 + 15) >> 4;  // FC1 output fragments (<= 3)
+    // ---- FC1: this wave owns k-groups g = wave, wave+16, ... ----
+    {
+        f4 xv[SE_MAXG], wv[SE_MAXG][3];
+#pragma unroll
+        for (int u = 0; u < SE_MAXG; ++u) {
+            const int k = (wave + 16 * u) * 16 + 4 * q;
+            const bool kok = k < C;
+            f4 x = {0.f, 0.f, 0.f, 0.f};
+            if (rok && kok) {
+                const float* xp = pool_part + (size_t)row * nslab * C + k;
+                f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+                int p = 0;
+                for (; p + 3 < nslab; p += 4) {
+                    s0 += *reinterpret_cast<const f4*>(xp + (size_t)p * C);
+                    s1 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 1) * C);
+                    s2 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 2) * C);
+                    s3 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 3) * C);
+                }
+                for (; p < nslab; ++p) s0 += *reinterpret_cast<const f4*>(xp + (size_t)p * C);
+                x = (s0 + s1) + (s2 + s3);
+            }
+            xv[u] = x;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int j = t * 16 + i;
+                f4 w = {0.f, 0.f, 0.f, 0.f};
+                if (kok && t < NJT && j < Cs4) w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + k);
+                wv[u][t] = w;
+            }
+        }
+        f4 acc[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < SE_MAXG; ++u)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t][s], xv[u][s], acc[t], 0, 0, 0);
+        // lane (i,q) holds outputs j = 16t + 4q + jj of row i
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (16 * t + 4 * q < 48) *reinterpret_cast<f4*>(&part[wave][i][16 * t + 4 * q]) = acc[t];
+    }
+    __syncthreads();
+    if (tid < 16 * 48) {
+        const int r = tid / 48, j = tid - r * 48;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += part[w][r][j];
+        rs[r][j] = (j < Cs4) ? silu_f(s + br[j]) : 0.f;
+    }
+    __syncthreads();
+    // ---- FC2: this wave owns output fragments t = wave, wave+16, ... ----
+    {
+        const int NKG = (Cs4 + 15) >> 4;  // k-groups (<= 3)
+        f4 xr[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(&rs[i][(g * 16 + 4 * q) % 48]);
+        f4 wv[SE_MAXT][3];
+#pragma unroll
+        for (int u = 0; u < SE_MAXT; ++u) {
+            const int n = (wave + 16 * u) * 16 + i;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int k = g * 16 + 4 * q;
+                f4 w = {0.f, 0.f, 0.f, 0.f};
+                if (n < C && g < NKG && k < Cs4) w = *reinterpret_cast<const f4*>(We + (size_t)n * Cs4 + k);
+                wv[u][g] = w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SE_MAXT; ++u) {
+            const int n0 = (wave + 16 * u) * 16;
+            if (n0 >= C) break;
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], (g * 16 + 4 * q + s < Cs4) ? xr[g][s] : 0.f, acc, 0, 0, 0);
+            if (rok) {
+                const int n = n0 + 4 * q;
+                const f4 bv = *reinterpret_cast<const f4*>(be + n);
+                f4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j] + bv[j]);
+                *reinterpret_cast<f4*>(gate + (size_t)row * C + n) = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Calibrated MLP head, fp32 end to end (the reference gate is max|dp| <= 1e-6, inference/export.py:31).
 // Y[m][n] = act( sum_k X[m][k] W[n][k] + b[n] ) on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
 // Lane (i=l&15, q=l>>4) loads 4 consecutive k of its row (16 B) and feeds element s at step s, so
@@ -972,18 +1088,11 @@ int launch_dwconv(const DwArgs& a, hipStream_t st)
 }
 
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* Wr, const float* br,
-                   const float* We, const float* be, float* rpart, int kz_slabs, float* gate, hipStream_t st)
+                   const float* We, const float* be, float* gate, hipStream_t st)
 {
-    // FC1 (reduce): [B x C] x [C x Cs4], split over K into kz_slabs partial slabs
-    const int kz = ((C + kz_slabs - 1) / kz_slabs + 15) / 16 * 16;
-    const int nz = (C + kz - 1) / kz;
-    dim3 g1((B + 63) / 64, (Cs4 + 63) / 64, nz);
-    hipLaunchKernelGGL((se_gemm_f32_kernel<1, 0>), g1, dim3(256), 0, st, pool_part, nparts, B, C, nullptr, Wr, nullptr,
-                       rpart, Cs4, kz);
-    LAUNCH_CHECK();
-    // FC2 (expand): silu(br + sum of slabs) [B x Cs4] x [Cs4 x C] -> sigmoid -> gate
-    dim3 g2((B + 63) / 64, (C + 63) / 64, 1);
-    hipLaunchKernelGGL((se_gemm_f32_kernel<2, 2>), g2, dim3(256), 0, st, rpart, nz, B, Cs4, br, We, be, gate, C, Cs4);
+    if (C > 16 * SE_MAXG * 16 || Cs4 > 48 || (C & 15)) return -6;
+    hipLaunchKernelGGL(se_fused_kernel, dim3((B + 15) / 16), dim3(1024), 0, st, pool_part, nparts, B, C, Cs4, Wr, br, We,
+                       be, gate);
     LAUNCH_CHECK();
     return 0;
 }

@@ -589,8 +589,8 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         snprintf(nm, sizeof nm, "b%d.dw", i);
         if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        STEP(nm, "se_gate", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
-                                           ws.se_r, (B.ce + 47) / 48 > 24 ? 24 : (B.ce + 47) / 48, ws.gate, st));
+        STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
+                                            ws.gate, st));
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
