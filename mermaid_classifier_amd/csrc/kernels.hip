@@ -509,11 +509,18 @@ __global__ __launch_bounds__(256) void se_gemm_f32_kernel(const float* __restric
 //   FC2  gate[16][C] = sigmoid(be + r . We^T): the 16 waves split the C/16 output fragments, r comes from LDS.
 // ---------------------------------------------------------------------------------------------
 #define SE_MAXG 5   // k-groups (16 k each) a wave may own in FC1: C <= 16 waves * 5 * 16 = 1280
-#define SE_MAXT 5   // output fragments a wave may own in FC2:     C <= 16 waves * 5 * 16 = 1280
+#define SE_MAXT 2   // output fragments a wave may own in FC2 (after the gridDim.y split)
+// Weights are fp32 (fp16 storage was tried: the gate error it causes is coherent per channel and
+// roughly doubled the end-to-end feature error), packed in MFMA fragment order (16 bytes per lane,
+// 1 KB per fragment, contiguous -> perfectly coalesced loads):
+//   WrP[(g*3 + t)*64 + lane][4] = Wr[16t + i][16g + 4q .. +4]      (zero for j >= Cs, carries 1/(HW log2e))
+//   WeP[(T*3 + g)*64 + lane][4] = We[16T + i][16g + 4q .. +4]      (zero for k >= Cs)
+// gridDim = (ceil(M/16), NSPLIT): every y-slice recomputes FC1 (cheap) and owns 1/NSPLIT of FC2's outputs,
+// so the weight stream of one patch group is spread over NSPLIT compute units.
 __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict__ pool_part, int nslab, int M, int C,
-                                                        int Cs4, const float* __restrict__ Wr,  // [Cs4][C]
-                                                        const float* __restrict__ br,           // [Cs4]
-                                                        const float* __restrict__ We,           // [C][Cs4]
+                                                        int Cs4, const float* __restrict__ WrP,
+                                                        const float* __restrict__ br,  // [48] zero padded
+                                                        const float* __restrict__ WeP,
                                                         const float* __restrict__ be, float* __restrict__ gate)
 {
     __shared__ __attribute__((aligned(16))) float part[16][16][48];  // [wave][row][j]
@@ -522,16 +529,18 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
     const int i = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 16 + i;
     const bool rok = row < M;
-    const int NJT = (Cs4 + 15) >> 4;  // FC1 output fragments (<= 3)
+    const int NG = C >> 4;            // k-groups of FC1 == output fragments of FC2
     // ---- FC1: this wave owns k-groups g = wave, wave+16, ... ----
     {
-        f4 xv[SE_MAXG], wv[SE_MAXG][3];
+        f4 xv[SE_MAXG];
+        f4 wv[SE_MAXG][3];
 #pragma unroll
         for (int u = 0; u < SE_MAXG; ++u) {
-            const int k = (wave + 16 * u) * 16 + 4 * q;
-            const bool kok = k < C;
+            const int g = wave + 16 * u;
+            const bool gok = g < NG;
+            const int k = g * 16 + 4 * q;
             f4 x = {0.f, 0.f, 0.f, 0.f};
-            if (rok && kok) {
+            if (rok && gok) {
                 const float* xp = pool_part + (size_t)row * nslab * C + k;
                 f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
                 int p = 0;
@@ -547,9 +556,8 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
             xv[u] = x;
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const int j = t * 16 + i;
                 f4 w = {0.f, 0.f, 0.f, 0.f};
-                if (kok && t < NJT && j < Cs4) w = *reinterpret_cast<const f4*>(Wr + (size_t)j * C + k);
+                if (gok) w = *reinterpret_cast<const f4*>(WrP + ((size_t)(g * 3 + t) * 64 + lane) * 4);
                 wv[u][t] = w;
             }
         }
@@ -565,8 +573,7 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t][s], xv[u][s], acc[t], 0, 0, 0);
         // lane (i,q) holds outputs j = 16t + 4q + jj of row i
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (16 * t + 4 * q < 48) *reinterpret_cast<f4*>(&part[wave][i][16 * t + 4 * q]) = acc[t];
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(&part[wave][i][16 * t + 4 * q]) = acc[t];
     }
     __syncthreads();
     if (tid < 16 * 48) {
@@ -577,36 +584,37 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
         rs[r][j] = (j < Cs4) ? silu_f(s + br[j]) : 0.f;
     }
     __syncthreads();
-    // ---- FC2: this wave owns output fragments t = wave, wave+16, ... ----
+    // ---- FC2: output fragments T = y*per_y + wave + 16u ----
     {
-        const int NKG = (Cs4 + 15) >> 4;  // k-groups (<= 3)
+        const int per_y = (NG + gridDim.y - 1) / gridDim.y;
+        const int t_lo = blockIdx.y * per_y;
+        const int t_hi = (t_lo + per_y) < NG ? (t_lo + per_y) : NG;
         f4 xr[3];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(&rs[i][(g * 16 + 4 * q) % 48]);
+        for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(&rs[i][g * 16 + 4 * q]);
         f4 wv[SE_MAXT][3];
 #pragma unroll
         for (int u = 0; u < SE_MAXT; ++u) {
-            const int n = (wave + 16 * u) * 16 + i;
+            const int T = t_lo + wave + 16 * u;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const int k = g * 16 + 4 * q;
                 f4 w = {0.f, 0.f, 0.f, 0.f};
-                if (n < C && g < NKG && k < Cs4) w = *reinterpret_cast<const f4*>(We + (size_t)n * Cs4 + k);
+                if (T < t_hi) w = *reinterpret_cast<const f4*>(WeP + ((size_t)(T * 3 + g) * 64 + lane) * 4);
                 wv[u][g] = w;
             }
         }
 #pragma unroll
         for (int u = 0; u < SE_MAXT; ++u) {
-            const int n0 = (wave + 16 * u) * 16;
-            if (n0 >= C) break;
+            const int T = t_lo + wave + 16 * u;
+            if (T >= t_hi) break;
             f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], (g * 16 + 4 * q + s < Cs4) ? xr[g][s] : 0.f, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], xr[g][s], acc, 0, 0, 0);
             if (rok) {
-                const int n = n0 + 4 * q;
+                const int n = T * 16 + 4 * q;
                 const f4 bv = *reinterpret_cast<const f4*>(be + n);
                 f4 o;
 #pragma unroll
@@ -1087,12 +1095,15 @@ int launch_dwconv(const DwArgs& a, hipStream_t st)
     return -4;
 }
 
-int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* Wr, const float* br,
-                   const float* We, const float* be, float* gate, hipStream_t st)
+int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* WrP, const float* br,
+                   const float* WeP, const float* be, float* gate, hipStream_t st)
 {
     if (C > 16 * SE_MAXG * 16 || Cs4 > 48 || (C & 15)) return -6;
-    hipLaunchKernelGGL(se_fused_kernel, dim3((B + 15) / 16), dim3(1024), 0, st, pool_part, nparts, B, C, Cs4, Wr, br, We,
-                       be, gate);
+    const int ng = C / 16;
+    int nsplit = (ng + 16 * SE_MAXT - 1) / (16 * SE_MAXT);   // each y-slice covers <= 16 waves * SE_MAXT fragments
+    if (ng >= 30 && nsplit < 4) nsplit = 4;                  // big layers: spread the weight stream over 4 CUs
+    hipLaunchKernelGGL(se_fused_kernel, dim3((B + 15) / 16, nsplit), dim3(1024), 0, st, pool_part, nparts, B, C, Cs4, WrP,
+                       br, WeP, be, gate);
     LAUNCH_CHECK();
     return 0;
 }

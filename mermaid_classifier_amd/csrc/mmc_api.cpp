@@ -102,7 +102,8 @@ struct BlockW {
     bool has_expand = false, skip = false;
     PwLayer expand, project;
     float *dw_w = nullptr, *dw_b = nullptr;                    // [k*k][ce], [ce]
-    float *se_wr = nullptr, *se_br = nullptr, *se_we = nullptr, *se_be = nullptr;
+    float *se_br = nullptr, *se_be = nullptr;
+    float *se_wrp = nullptr, *se_wep = nullptr;   // fragment-ordered fp32 squeeze-excite weights
     // depthwise launch geometry
     int tw = 0, CG = 0, S = 0, iters = 0, parts = 0;
     // fused expand+depthwise (mbconv_a_kernel) geometry; fused == false -> separate GEMM + dwconv
@@ -356,21 +357,29 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(br, B.cs, nm);
             TAKE(we, (size_t)B.ce * B.cs, nm);
             TAKE(be, B.ce, nm);
-            // FC1 weights [cs4][ce]: rows padded to a multiple of 4 outputs (zero rows -> silu(0) = 0), scaled by
-            // 1/(HW*log2e): the pooled sums are over HW pixels of log2(e)-scaled activations.
+            // Squeeze-excite weights, fp32 in MFMA fragment order (se_fused_kernel): 3 output/k fragments of 16
+            // cover Cs <= 48.  FC1 carries 1/(HW*log2e): the pooled sums are over HW pixels of log2(e)-scaled
+            // activations.
             B.cs4 = (B.cs + 3) / 4 * 4;
             const double psc = 1.0 / ((double)B.Ho * B.Ho * LOG2E);
-            std::vector<float> wrs((size_t)B.cs4 * B.ce, 0.f), brs(B.cs4, 0.f);
-            for (int j = 0; j < B.cs; ++j) {
-                for (int c = 0; c < B.ce; ++c) wrs[(size_t)j * B.ce + c] = (float)(wr[(size_t)j * B.ce + c] * psc);
-                brs[j] = br[j];
-            }
-            TRY_OR_FREE(dev_upload(bb, &B.se_wr, wrs));
+            const int ng = B.ce / 16;
+            std::vector<float> wrp((size_t)ng * 3 * 64 * 4, 0.f), wep((size_t)ng * 3 * 64 * 4, 0.f);
+            for (int g = 0; g < ng; ++g)
+                for (int t = 0; t < 3; ++t)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int e = 0; e < 4; ++e) {
+                            const int ii = ln & 15, qq = ln >> 4;
+                            const size_t off = (((size_t)g * 3 + t) * 64 + ln) * 4 + e;
+                            const int j = 16 * t + ii, c = 16 * g + 4 * qq + e;         // FC1: Wr[j][c]
+                            if (j < B.cs) wrp[off] = (float)(wr[(size_t)j * B.ce + c] * psc);
+                            const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
+                            if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
+                        }
+            TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
+            TRY_OR_FREE(dev_upload(bb, &B.se_wep, wep));
+            std::vector<float> brs(48, 0.f);
+            for (int j = 0; j < B.cs; ++j) brs[j] = br[j];
             TRY_OR_FREE(dev_upload(bb, &B.se_br, brs));
-            std::vector<float> wes((size_t)B.ce * B.cs4, 0.f);   // FC2 weights [ce][cs4], zero-padded columns
-            for (int c = 0; c < B.ce; ++c)
-                for (int j = 0; j < B.cs; ++j) wes[(size_t)c * B.cs4 + j] = we[(size_t)c * B.cs + j];
-            TRY_OR_FREE(dev_upload(bb, &B.se_we, wes));
             TRY_OR_FREE(dev_upload(bb, &B.se_be, std::vector<float>(be, be + B.ce)));
         }
         {
@@ -589,7 +598,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         snprintf(nm, sizeof nm, "b%d.dw", i);
         if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wr, B.se_br, B.se_we, B.se_be,
+        STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wrp, B.se_br, B.se_wep, B.se_be,
                                             ws.gate, st));
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
         snprintf(nm, sizeof nm, "b%d.project", i);
