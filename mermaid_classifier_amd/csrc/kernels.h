@@ -42,7 +42,7 @@ struct MbArgs {
     _Float16* out;          // [B][Ho][Wo][Ce]
     float* pool_part;       // [B][tiles][Ce]
     int B, H, W, Cin, Ce, Ho, Wo, pad;
-    int ks, stride, tw, ksteps, npair;
+    int ks, stride, tw, ksteps, npair, pb;
     int TH, TWo, tiles_x, tiles_y, CC, CCG, S;
     int wl_off, red_off, lds_bytes;
 };

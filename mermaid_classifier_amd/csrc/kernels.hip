@@ -802,7 +802,9 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
 // CC (channels per chunk) and TWO (output tile width) are template parameters so that every row
 // stride, channel-group split and strip decode is constant arithmetic: the kernel is VALU-bound and
 // runtime integer multiplies/divides were ~half of its instruction stream.
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO>
+// PB > 1 (whole-image tiles only: 7x7 layers): one workgroup takes PB consecutive patches, so the chunk's
+// weight fragments are streamed once per PB patches and all four waves have MFMA fragments to work on.
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB>
 __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
                                                        const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
                                                        const float* __restrict__ bexp,     // [Ce]
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                                                        _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
                                                        float* __restrict__ pool_part,      // [B][ntiles][Ce]
                                                        int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
-                                                       int tiles_x, int wl_off, int red_off)
+                                                       int tiles_x, int wl_off, int red_off, int nB)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Kp = 32 * KSTEPS;
@@ -820,7 +822,8 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     constexpr int NTC = CC / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z * PB;
+    const int nb = (nB - b) < PB ? (nB - b) : PB;   // patches this workgroup really has
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TWo;
     // input window of this tile, clipped to the image
@@ -831,7 +834,8 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     wy1 = wy1 > H ? H : wy1;
     wx1 = wx1 > W ? W : wx1;
     const int ww = wx1 - wx0;
-    const int P = (wy1 - wy0) * ww;
+    const int P1 = (wy1 - wy0) * ww;                // positions of one patch's window
+    const int P = (PB > 1 ? nb : 1) * P1;           // PB > 1: windows are whole images, stacked patch after patch
     const unsigned wmagic = (65536u + ww - 1) / ww;  // p / ww == (p * wmagic) >> 16 for p < 65536 / ww
     float* wl = reinterpret_cast<float*>(smem + wl_off);    // [KS*KS][CC] depthwise taps of this chunk, then bias [CC]
     float* bl = wl + KS * KS * CC;                          // expand bias of this chunk
@@ -846,8 +850,13 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
             const int pp = ((pr * 4 + wave) * 2 + i) * 16 + m;
             p[pr][i] = pp;
             const bool ok = pp < P;
-            const int py = ok ? (int)(((unsigned)pp * wmagic) >> 16) : 0, px = ok ? pp - py * ww : 0;
-            const _Float16* xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
+            const _Float16* xp;
+            if (PB > 1) {   // whole images: position pp of the group is row b*H*W + pp of the NHWC tensor
+                xp = X + ((size_t)b * H * W + (ok ? pp : 0)) * Cin + q * 8;
+            } else {
+                const int py = ok ? (int)(((unsigned)pp * wmagic) >> 16) : 0, px = ok ? pp - py * ww : 0;
+                xp = X + (((size_t)b * H + wy0 + py) * W + wx0 + px) * Cin + q * 8;
+            }
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -904,9 +913,11 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     const int cglob = chunk * CC + cg * 8;
     constexpr int spr = TWo / TW;
     const int nstrips = TH * spr;
-    float pooled[8];
+    float pooled[PB][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pooled[j] = 0.f;
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pooled[pb][j] = 0.f;
     if (active) {
         float bs[8];
         {
@@ -916,72 +927,81 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
             for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
         }
         constexpr int NX = (TW - 1) * ST + KS;
-        _Float16* outb = out + (size_t)b * Ho * Wo * Ce + cglob;
-        for (int strip = s; strip < nstrips; strip += S) {
-            const int oyl = strip / spr;
-            const int oy = oy0 + oyl, ox = ox0 + (strip - oyl * spr) * TW;
-            float acc[TW][8];
 #pragma unroll
-            for (int t = 0; t < TW; ++t)
+        for (int pb = 0; pb < PB; ++pb) {
+            if (pb >= nb) break;
+            _Float16* outb = out + (size_t)(b + pb) * Ho * Wo * Ce + cglob;
+            const int ebase = pb * P1;   // first E row of this patch
+            for (int strip = s; strip < nstrips; strip += S) {
+                const int oyl = strip / spr;
+                const int oy = oy0 + oyl, ox = ox0 + (strip - oyl * spr) * TW;
+                float acc[TW][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
 #pragma unroll 1
-            for (int ky = 0; ky < KS; ++ky) {
-                const int iy = oy * ST - pad + ky;
-                if (iy < 0 || iy >= H) continue;
-                const int rbase = (iy - wy0) * ww - wx0;  // E row of (iy, ix) is rbase + ix
-                float wk[KS][8];
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int iy = oy * ST - pad + ky;
+                    if (iy < 0 || iy >= H) continue;
+                    const int rbase = ebase + (iy - wy0) * ww - wx0;  // E row of (iy, ix) is rbase + ix
+                    float wk[KS][8];
 #pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const f4 w0 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8);
-                    const f4 w1 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8 + 4);
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f4 w0 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8);
+                        const f4 w1 = *reinterpret_cast<const f4*>(wl + (ky * KS + kx) * CC + cg * 8 + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
-                }
+                        for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
+                    }
 #pragma unroll
-                for (int xr = 0; xr < NX; ++xr) {
-                    const int ix = ox * ST - pad + xr;
-                    uint4 v = {0u, 0u, 0u, 0u};
-                    if (ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(smem + (rbase + ix) * ES + cg * 16);
+                    for (int xr = 0; xr < NX; ++xr) {
+                        const int ix = ox * ST - pad + xr;
+                        uint4 v = {0u, 0u, 0u, 0u};
+                        if (ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(smem + (rbase + ix) * ES + cg * 16);
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) {
-                        const int kx = xr - t * ST;
-                        if (kx >= 0 && kx < KS) {
-                            acc[t][0] = fma_mix_lo(v.x, wk[kx][0], acc[t][0]);
-                            acc[t][1] = fma_mix_hi(v.x, wk[kx][1], acc[t][1]);
-                            acc[t][2] = fma_mix_lo(v.y, wk[kx][2], acc[t][2]);
-                            acc[t][3] = fma_mix_hi(v.y, wk[kx][3], acc[t][3]);
-                            acc[t][4] = fma_mix_lo(v.z, wk[kx][4], acc[t][4]);
-                            acc[t][5] = fma_mix_hi(v.z, wk[kx][5], acc[t][5]);
-                            acc[t][6] = fma_mix_lo(v.w, wk[kx][6], acc[t][6]);
-                            acc[t][7] = fma_mix_hi(v.w, wk[kx][7], acc[t][7]);
+                        for (int t = 0; t < TW; ++t) {
+                            const int kx = xr - t * ST;
+                            if (kx >= 0 && kx < KS) {
+                                acc[t][0] = fma_mix_lo(v.x, wk[kx][0], acc[t][0]);
+                                acc[t][1] = fma_mix_hi(v.x, wk[kx][1], acc[t][1]);
+                                acc[t][2] = fma_mix_lo(v.y, wk[kx][2], acc[t][2]);
+                                acc[t][3] = fma_mix_hi(v.y, wk[kx][3], acc[t][3]);
+                                acc[t][4] = fma_mix_lo(v.z, wk[kx][4], acc[t][4]);
+                                acc[t][5] = fma_mix_hi(v.z, wk[kx][5], acc[t][5]);
+                                acc[t][6] = fma_mix_lo(v.w, wk[kx][6], acc[t][6]);
+                                acc[t][7] = fma_mix_hi(v.w, wk[kx][7], acc[t][7]);
+                            }
                         }
                     }
                 }
-            }
 #pragma unroll
-            for (int t = 0; t < TW; ++t) {
-                h8 o;
+                for (int t = 0; t < TW; ++t) {
+                    h8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = silu_scaled(acc[t][j]);
-                    pooled[j] += y;
-                    o[j] = (_Float16)y;
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = silu_scaled(acc[t][j]);
+                        pooled[pb][j] += y;
+                        o[j] = (_Float16)y;
+                    }
+                    *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox + t) * Ce) = o;
                 }
-                *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox + t) * Ce) = o;
             }
         }
     }
-    __syncthreads();  // every wave is done reading E: its space is reused for the pool scratch
+    __syncthreads();  // every wave is done reading E: its space is reused for the pool scratch [PB][S][CC]
     if (active) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[s * CC + cg * 8 + j] = pooled[j];
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(pb * S + s) * CC + cg * 8 + j] = pooled[pb][j];
     }
     __syncthreads();
-    for (int c = tid; c < CC; c += 256) {
+    for (int e = tid; e < PB * CC; e += 256) {
+        const int pb = e / CC, c = e - pb * CC;
+        if (pb >= nb) continue;
         float sum = 0.f;
-        for (int ss = 0; ss < S; ++ss) sum += red[ss * CC + c];
-        pool_part[((size_t)b * gridDim.x + tile) * Ce + chunk * CC + c] = sum;
+        for (int ss = 0; ss < S; ++ss) sum += red[(pb * S + ss) * CC + c];
+        pool_part[((size_t)(b + pb) * gridDim.x + tile) * Ce + chunk * CC + c] = sum;
     }
 }
 
@@ -1137,34 +1157,39 @@ int launch_crop(const uint8_t* image, int H, int W, const int32_t* rowcols, int 
     return 0;
 }
 
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO>
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB>
 static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
 {
-    dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, a.B);
-    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO>), grid, dim3(256), a.lds_bytes, st, a.X,
+    dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, (a.B + PB - 1) / PB);
+    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB>), grid, dim3(256), a.lds_bytes, st, a.X,
                        a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH,
-                       a.tiles_x, a.wl_off, a.red_off);
+                       a.tiles_x, a.wl_off, a.red_off, a.B);
     LAUNCH_CHECK();
     return 0;
 }
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st)
 {
-#define MB_CASE(KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_)                                                   \
+    if (a.pb > 1 && (a.tiles_x * a.tiles_y != 1 || a.TH != a.Ho || a.TWo != a.Wo)) return -8;
+#define MB_CASE(KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_, PB_)                                              \
     if (a.ks == KS_ && a.stride == ST_ && a.tw == TW_ && a.ksteps == KSTEPS_ && a.npair == NPAIR_ &&         \
-        a.CC == CC_ && a.TWo == TWO_)                                                                        \
-        return launch_mbconv_t<KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_>(a, st);
-    MB_CASE(3, 2, 2, 1, 3, 48, 8)     // b1
-    MB_CASE(3, 1, 2, 1, 2, 48, 14)    // b2
-    MB_CASE(5, 2, 2, 1, 3, 48, 14)    // b3
-    MB_CASE(5, 1, 2, 2, 3, 48, 14)    // b4
-    MB_CASE(3, 2, 2, 2, 2, 80, 14)    // b5
-    MB_CASE(3, 1, 2, 3, 2, 96, 14)    // b6, b7
-    MB_CASE(5, 1, 2, 3, 2, 96, 14)    // b8
-    MB_CASE(5, 1, 2, 4, 2, 96, 14)    // b9, b10
-    MB_CASE(5, 2, 1, 4, 2, 96, 7)     // b11
-    MB_CASE(5, 1, 1, 6, 1, 192, 7)    // b12-b14
-    MB_CASE(3, 1, 1, 6, 1, 192, 7)    // b15
+        a.CC == CC_ && a.TWo == TWO_ && a.pb == PB_)                                                         \
+        return launch_mbconv_t<KS_, ST_, TW_, KSTEPS_, NPAIR_, CC_, TWO_, PB_>(a, st);
+    MB_CASE(3, 2, 2, 1, 3, 48, 8, 1)     // b1
+    MB_CASE(3, 1, 2, 1, 2, 48, 14, 1)    // b2
+    MB_CASE(5, 2, 2, 1, 3, 48, 14, 1)    // b3
+    MB_CASE(5, 1, 2, 2, 3, 48, 14, 1)    // b4
+    MB_CASE(3, 2, 2, 2, 2, 80, 14, 1)    // b5
+    MB_CASE(3, 1, 2, 3, 2, 96, 14, 1)    // b6, b7
+    MB_CASE(5, 1, 2, 3, 2, 96, 14, 1)    // b8
+    MB_CASE(5, 1, 2, 4, 2, 96, 14, 1)    // b9, b10
+    MB_CASE(5, 2, 1, 4, 2, 96, 7, 1)     // b11
+    MB_CASE(5, 1, 1, 6, 1, 192, 7, 1)    // b12-b14, one patch per workgroup
+    MB_CASE(3, 1, 1, 6, 1, 192, 7, 1)    // b15
+    MB_CASE(5, 1, 1, 6, 1, 96, 7, 2)     // b12-b14, two patches per workgroup
+    MB_CASE(3, 1, 1, 6, 1, 96, 7, 2)     // b15
+    MB_CASE(5, 1, 1, 6, 2, 96, 7, 4)     // b12-b14, four patches per workgroup
+    MB_CASE(3, 1, 1, 6, 2, 96, 7, 4)     // b15
 #undef MB_CASE
     return -5;
 }

@@ -110,17 +110,17 @@ struct BlockW {
     bool fused = false;
     _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
     int f_TH = 0, f_TWo = 0, f_CC = 0, f_tw = 0, f_ksteps = 0, f_CCG = 0, f_S = 0, f_tiles_x = 0, f_tiles_y = 0,
-        f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0;
+        f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0, f_pb = 1;
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
 // chosen so that E[P][CC] + the pool scratch stay <= 64 KB of LDS (>= 2 workgroups per CU) while
 // the halo recompute and the per-chunk re-read of the (small) block input stay low.
-struct FuseCfg { int TH, TWo, CC, TW; };
+struct FuseCfg { int TH, TWo, CC, TW, PB; };
 static const FuseCfg B0_FUSE[16] = {
-    {0, 0, 0, 0},     {8, 8, 48, 2},    {14, 14, 48, 2},  {4, 14, 48, 2},   {14, 14, 48, 2},  {2, 14, 80, 2},
-    {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {14, 14, 96, 2},  {7, 7, 96, 1},
-    {7, 7, 192, 1},   {7, 7, 192, 1},   {7, 7, 192, 1},   {7, 7, 192, 1}};
+    {0, 0, 0, 0, 1},     {8, 8, 48, 2, 1},    {14, 14, 48, 2, 1},  {4, 14, 48, 2, 1},   {14, 14, 48, 2, 1},  {2, 14, 80, 2, 1},
+    {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {7, 7, 96, 1, 1},
+    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2}};
 
 struct Saved {
     void* dev = nullptr;
@@ -403,7 +403,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 snprintf(key, sizeof key, "%d:", i);
                 const char* hit = strstr(ov, key);
                 while (hit && hit != ov && hit[-1] != ';') hit = strstr(hit + 1, key);
-                if (hit) sscanf(hit + strlen(key), "%d,%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC, &fc.TW);
+                if (hit) sscanf(hit + strlen(key), "%d,%d,%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC, &fc.TW, &fc.PB);
             }
             if (fc.TH > 0 && B.Ho % fc.TH == 0 && B.Ho % fc.TWo == 0 && B.ce % fc.CC == 0 && fc.CC % 16 == 0) {
                 B.f_TH = fc.TH; B.f_TWo = fc.TWo; B.f_CC = fc.CC;
@@ -415,12 +415,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 int wh = (fc.TH - 1) * B.d.s + B.d.k, wwid = (fc.TWo - 1) * B.d.s + B.d.k;
                 if (wh > H) wh = H;
                 if (wwid > H) wwid = H;
-                const int ppad = (wh * wwid + 15) / 16 * 16;
+                B.f_pb = fc.PB < 1 ? 1 : fc.PB;
+                const int ppad = (B.f_pb * wh * wwid + 15) / 16 * 16;
                 B.f_npair = (ppad / 16 + 7) / 8;
                 B.f_wl_off = ppad * (fc.CC * 2 + 16);
                 B.f_red_off = 0;  // pool scratch aliases E (S*CC*4 = 8 KB <= E)
                 B.f_lds = B.f_wl_off + (B.d.k * B.d.k + 1) * fc.CC * 4;
-                if (B.f_S * fc.CC * 4 > B.f_wl_off) B.f_lds = 1 << 30;
+                if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wl_off) B.f_lds = 1 << 30;
                 const int kp = 32 * B.f_ksteps;
                 if (B.f_lds <= 64 * 1024 && fc.TWo % B.f_tw == 0) {
                     std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
@@ -570,12 +571,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             a.pool_part = ws.pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
             a.Wo = B.Ho; a.pad = B.pad; a.ks = B.d.k; a.stride = B.d.s; a.tw = B.f_tw; a.ksteps = B.f_ksteps;
             a.TH = B.f_TH; a.TWo = B.f_TWo; a.tiles_x = B.f_tiles_x; a.tiles_y = B.f_tiles_y; a.CC = B.f_CC;
-            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair;
+            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair; a.pb = B.f_pb;
             a.wl_off = B.f_wl_off;
             nparts = B.f_tiles_x * B.f_tiles_y;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char fl[48];
-            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair);
+            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb);
             STEP(nm, fl, launch_mbconv_a(a, st));
         } else {
             const _Float16* dw_in = x;
