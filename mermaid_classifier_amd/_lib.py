@@ -35,6 +35,14 @@ def _load() -> C.CDLL:
         raise LibraryMissingError(
             f"{path} not found: build it with `python -m mermaid_classifier_amd.build` "
             "(hipcc --offload-arch=gfx950). mermaid_classifier_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not share
+    # devices, so make sure torch's copy is the one already resident before our library resolves its
+    # libamdhip64 dependency (otherwise /opt/rocm's would load first and torch tensors would live in a
+    # different runtime than our kernels).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(path))
     vp, i32, i64, u32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint, C.c_size_t
     fp = C.POINTER(C.c_float)

@@ -36,6 +36,7 @@ struct DwArgs {
 struct MbArgs {
     const _Float16* X;      // [B][H][W][Cin]
     const _Float16* Wexp;   // [Ce][32*ksteps] natural rows, zero-padded K
+    const _Float16* Wfrag;  // the same weights in MFMA fragment order [Ce/16][ksteps][64][8] (wlds)
     const float* bexp;
     const float* Wdw;       // [ks*ks][Ce]
     const float* bdw;
@@ -44,7 +45,7 @@ struct MbArgs {
     int B, H, W, Cin, Ce, Ho, Wo, pad;
     int ks, stride, tw, ksteps, npair, pb;
     int TH, TWo, tiles_x, tiles_y, CC, CCG, S;
-    int wl_off, red_off, lds_bytes;
+    int wl_off, red_off, lds_bytes, wlds, wfr_off;
 };
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);

@@ -804,7 +804,9 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
 // runtime integer multiplies/divides were ~half of its instruction stream.
 // PB > 1 (whole-image tiles only: 7x7 layers): one workgroup takes PB consecutive patches, so the chunk's
 // weight fragments are streamed once per PB patches and all four waves have MFMA fragments to work on.
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB>
+// WLDS: the chunk's expand weights (fragment order, Wfrag) are copied to LDS in one burst at kernel start and
+// read back lane-linearly per MFMA; otherwise fragments stream from L2 (Wexp rows), one fragment ahead.
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB, bool WLDS>
 __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
                                                        const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
                                                        const float* __restrict__ bexp,     // [Ce]
@@ -813,7 +815,8 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                                                        _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
                                                        float* __restrict__ pool_part,      // [B][ntiles][Ce]
                                                        int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
-                                                       int tiles_x, int wl_off, int red_off, int nB)
+                                                       int tiles_x, int wl_off, int red_off, int nB,
+                                                       const _Float16* __restrict__ Wfrag, int wfr_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int Kp = 32 * KSTEPS;
@@ -864,6 +867,11 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 xf[pr][i][ks] = v;
             }
         }
+    if (WLDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(Wfrag + (size_t)chunk * NTC * KSTEPS * 512);
+        uint4* dst = reinterpret_cast<uint4*>(smem + wfr_off);
+        for (int i = tid; i < NTC * KSTEPS * 64; i += 256) dst[i] = src[i];
+    }
     for (int i = tid; i < KS * KS * CC; i += 256) {
         const int tap = i / CC, c = i - tap * CC;
         wl[i] = Wdw[(size_t)tap * Ce + chunk * CC + c];
@@ -873,17 +881,26 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     // ---------------- phase 1: expand GEMM into LDS ----------------
     {
         const _Float16* wbase = Wexp + ((size_t)chunk * CC + m) * Kp + q * 8;
+        const _Float16* wfr = reinterpret_cast<const _Float16*>(smem + wfr_off);
         h8 wn[KSTEPS];
+        if (!WLDS) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) wn[ks] = *reinterpret_cast<const h8*>(wbase + ks * 32);
+            for (int ks = 0; ks < KSTEPS; ++ks) wn[ks] = *reinterpret_cast<const h8*>(wbase + ks * 32);
+        }
         for (int t = 0; t < NTC; ++t) {
             h8 wc[KSTEPS];
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) wc[ks] = wn[ks];
-            if (t + 1 < NTC) {
+            if (WLDS) {
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks)
-                    wn[ks] = *reinterpret_cast<const h8*>(wbase + (size_t)(t + 1) * 16 * Kp + ks * 32);
+                    wc[ks] = *reinterpret_cast<const h8*>(wfr + ((t * KSTEPS + ks) * 64 + lane) * 8);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) wc[ks] = wn[ks];
+                if (t + 1 < NTC) {
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ++ks)
+                        wn[ks] = *reinterpret_cast<const h8*>(wbase + (size_t)(t + 1) * 16 * Kp + ks * 32);
+                }
             }
             const f4 bv = *reinterpret_cast<const f4*>(bl + t * 16 + 4 * q);  // bias = accumulator init
 #pragma unroll
@@ -1161,9 +1178,23 @@ template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB
 static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
 {
     dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, (a.B + PB - 1) / PB);
-    hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB>), grid, dim3(256), a.lds_bytes, st, a.X,
-                       a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH,
-                       a.tiles_x, a.wl_off, a.red_off, a.B);
+    if (a.wlds) {
+        static bool attr_done = false;  // more than the default 64 KB of dynamic LDS
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB, true>), grid, dim3(256), a.lds_bytes,
+                           st, a.X, a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo,
+                           a.pad, a.TH, a.tiles_x, a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off);
+    } else {
+        hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB, false>), grid, dim3(256), a.lds_bytes,
+                           st, a.X, a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo,
+                           a.pad, a.TH, a.tiles_x, a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off);
+    }
     LAUNCH_CHECK();
     return 0;
 }
@@ -1188,8 +1219,6 @@ int launch_mbconv_a(const MbArgs& a, hipStream_t st)
     MB_CASE(3, 1, 1, 6, 1, 192, 7, 1)    // b15
     MB_CASE(5, 1, 1, 6, 1, 96, 7, 2)     // b12-b14, two patches per workgroup
     MB_CASE(3, 1, 1, 6, 1, 96, 7, 2)     // b15
-    MB_CASE(5, 1, 1, 6, 2, 96, 7, 4)     // b12-b14, four patches per workgroup
-    MB_CASE(3, 1, 1, 6, 2, 96, 7, 4)     // b15
 #undef MB_CASE
     return -5;
 }

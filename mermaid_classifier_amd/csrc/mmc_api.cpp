@@ -110,17 +110,19 @@ struct BlockW {
     bool fused = false;
     _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
     int f_TH = 0, f_TWo = 0, f_CC = 0, f_tw = 0, f_ksteps = 0, f_CCG = 0, f_S = 0, f_tiles_x = 0, f_tiles_y = 0,
-        f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0, f_pb = 1;
+        f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0, f_pb = 1, f_wlds = 0, f_wfr_off = 0;
+    _Float16* exp_frag = nullptr;  // expand weights in MFMA fragment order
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
 // chosen so that E[P][CC] + the pool scratch stay <= 64 KB of LDS (>= 2 workgroups per CU) while
 // the halo recompute and the per-chunk re-read of the (small) block input stay low.
-struct FuseCfg { int TH, TWo, CC, TW, PB; };
+struct FuseCfg { int TH, TWo, CC, TW, PB, WLDS; };
 static const FuseCfg B0_FUSE[16] = {
-    {0, 0, 0, 0, 1},     {8, 8, 48, 2, 1},    {14, 14, 48, 2, 1},  {4, 14, 48, 2, 1},   {14, 14, 48, 2, 1},  {2, 14, 80, 2, 1},
-    {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {14, 14, 96, 2, 1},  {7, 7, 96, 1, 1},
-    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2},    {7, 7, 96, 1, 2}};
+    {0, 0, 0, 0, 1, 0},     {8, 8, 48, 2, 1, 0},    {14, 14, 48, 2, 1, 0},  {4, 14, 48, 2, 1, 0},   {14, 14, 48, 2, 1, 0},
+    {2, 14, 80, 2, 1, 0},   {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},
+    {14, 14, 96, 2, 1, 0},  {7, 7, 96, 1, 1, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},
+    {7, 7, 96, 1, 2, 0}};
 
 struct Saved {
     void* dev = nullptr;
@@ -140,7 +142,7 @@ struct mmc_backbone {
     // one lane (squeeze-excite FCs, 7x7 layers) overlap the bandwidth/VALU-bound launches of the other.
     struct Lane {
         _Float16 *act0 = nullptr, *act1 = nullptr, *expbuf = nullptr, *dwbuf = nullptr;
-        float *pool_part = nullptr, *gate = nullptr, *se_r = nullptr;
+        float *pool_part = nullptr, *gate = nullptr;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
     };
@@ -403,7 +405,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 snprintf(key, sizeof key, "%d:", i);
                 const char* hit = strstr(ov, key);
                 while (hit && hit != ov && hit[-1] != ';') hit = strstr(hit + 1, key);
-                if (hit) sscanf(hit + strlen(key), "%d,%d,%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC, &fc.TW, &fc.PB);
+                if (hit) sscanf(hit + strlen(key), "%d,%d,%d,%d,%d,%d", &fc.TH, &fc.TWo, &fc.CC, &fc.TW, &fc.PB, &fc.WLDS);
             }
             if (fc.TH > 0 && B.Ho % fc.TH == 0 && B.Ho % fc.TWo == 0 && B.ce % fc.CC == 0 && fc.CC % 16 == 0) {
                 B.f_TH = fc.TH; B.f_TWo = fc.TWo; B.f_CC = fc.CC;
@@ -418,16 +420,25 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 B.f_pb = fc.PB < 1 ? 1 : fc.PB;
                 const int ppad = (B.f_pb * wh * wwid + 15) / 16 * 16;
                 B.f_npair = (ppad / 16 + 7) / 8;
-                B.f_wl_off = ppad * (fc.CC * 2 + 16);
-                B.f_red_off = 0;  // pool scratch aliases E (S*CC*4 = 8 KB <= E)
+                B.f_wlds = fc.WLDS ? 1 : 0;
+                B.f_wfr_off = ppad * (fc.CC * 2 + 16);                       // E | [weight fragments] | taps+bias
+                B.f_wl_off = B.f_wfr_off + (B.f_wlds ? (fc.CC / 16) * B.f_ksteps * 1024 : 0);
+                B.f_red_off = 0;  // pool scratch aliases E
                 B.f_lds = B.f_wl_off + (B.d.k * B.d.k + 1) * fc.CC * 4;
-                if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wl_off) B.f_lds = 1 << 30;
+                if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wfr_off) B.f_lds = 1 << 30;
                 const int kp = 32 * B.f_ksteps;
-                if (B.f_lds <= 64 * 1024 && fc.TWo % B.f_tw == 0) {
+                if (B.f_lds <= (B.f_wlds ? 128 : 64) * 1024 && fc.TWo % B.f_tw == 0) {
                     std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
                     for (int c = 0; c < B.ce; ++c)
                         for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)(float)(exp_w_host[(size_t)c * B.d.cin + k] * LOG2E);
                     TRY_OR_FREE(dev_upload(bb, &B.exp_nat, wn));
+                    {   // fragment order: ((c/16 * ksteps + k/32) * 64 + (k%32)/8 * 16 + c%16) * 8 + k%8
+                        std::vector<_Float16> wf((size_t)B.ce * kp, (_Float16)0.0f);
+                        for (int c = 0; c < B.ce; ++c)
+                            for (int k = 0; k < B.d.cin; ++k)
+                                wf[((((size_t)(c / 16) * B.f_ksteps + k / 32) * 64) + ((k % 32) / 8) * 16 + (c % 16)) * 8 + (k % 8)] = wn[(size_t)c * kp + k];
+                        TRY_OR_FREE(dev_upload(bb, &B.exp_frag, wf));
+                    }
                     B.fused = true;
                     const size_t pp = (size_t)B.f_tiles_x * B.f_tiles_y * B.ce;
                     if (pp > max_pool) max_pool = pp;
@@ -468,7 +479,6 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TRY_OR_FREE(dev_alloc(bb, &L.dwbuf, lc * max_dw));
             TRY_OR_FREE(dev_alloc(bb, &L.pool_part, lc * max_pool));
             TRY_OR_FREE(dev_alloc(bb, &L.gate, lc * (size_t)max_c));
-            TRY_OR_FREE(dev_alloc(bb, &L.se_r, lc * (size_t)48 * 24));   // up to 24 split-K slabs of [n][cs4<=48]
             if (nl > 1) {
                 if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
                     hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) {
@@ -571,12 +581,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             a.pool_part = ws.pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;
             a.Wo = B.Ho; a.pad = B.pad; a.ks = B.d.k; a.stride = B.d.s; a.tw = B.f_tw; a.ksteps = B.f_ksteps;
             a.TH = B.f_TH; a.TWo = B.f_TWo; a.tiles_x = B.f_tiles_x; a.tiles_y = B.f_tiles_y; a.CC = B.f_CC;
-            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair; a.pb = B.f_pb;
+            a.CCG = B.f_CCG; a.S = B.f_S; a.red_off = B.f_red_off; a.lds_bytes = B.f_lds; a.npair = B.f_npair; a.pb = B.f_pb; a.wlds = B.f_wlds; a.wfr_off = B.f_wfr_off; a.Wfrag = B.exp_frag;
             a.wl_off = B.f_wl_off;
             nparts = B.f_tiles_x * B.f_tiles_y;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char fl[48];
-            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb);
+            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb, a.wlds);
             STEP(nm, fl, launch_mbconv_a(a, st));
         } else {
             const _Float16* dw_in = x;

@@ -149,3 +149,26 @@ def test_extract_then_classify_labels_match_oracle_chain(backbone, oracle_net):
     assert np.array_equal(got.argmax(1)[decided], want.argmax(1)[decided])
     # same features in -> identical labels, always
     assert np.array_equal(pred.predict_proba(f_ref).argmax(1), want.argmax(1))
+
+
+def test_cross_image_batching_matches_per_image_oracle(backbone, oracle_net):
+    """BASELINE config 3 in miniature: several images x several points through the cross-image batcher
+    (GPU crop + large passes) == the oracle's per-image crop + forward, image by image, point order kept;
+    ragged point counts, an image without points, and a buffer smaller than one image's points."""
+    from mermaid_classifier_amd.pipeline import BatchedExtractor
+    from oracle import pyspacer_ref
+    rng = np.random.default_rng(11)
+    images = [rng.integers(0, 255, (300 + 17 * i, 420 - 11 * i, 3), dtype=np.uint8) for i in range(4)]
+    rowcols = [[(0, 0), (150, 200), (299, 419)], [], [(10, 20), (300, 5), (7, 390), (160, 160), (333, 397)],
+               [(int(r), int(c)) for r, c in zip(rng.integers(0, 351, 9), rng.integers(0, 387, 9))]]
+    ex = BatchedExtractor(backbone, batch_patches=6)       # forces flushes inside an image
+    got = ex.extract_images(images, rowcols)
+    assert [g.shape for g in got] == [(3, 1280), (0, 1280), (5, 1280), (9, 1280)]
+    for im, rc, g in zip(images, rowcols, got):
+        if rc:
+            want = pyspacer_ref.extract(oracle_net, im, rc)
+            assert cosine(g, want).min() >= COS_GATE and rel_l2(g, want).max() < TOL_NOISE
+    feats = ex.extract_image_features(images[:1], rowcols[:1])[0]
+    assert feats.npoints == 3 and np.allclose(feats.get_array((150, 200)), got[0][1])
+    with pytest.raises(ValueError):
+        ex.extract_images(images[:1], [[(400, 1)]])

@@ -193,3 +193,30 @@ def test_extractor_constructor_shapes(checkpoint_path):
         build_extractor_class()(data_locations={}, device="cuda", batch_size=10)
     with pytest.raises(ValueError):
         build_extractor_class()(data_locations={"weights": loc}, device="cuda", batch_size=0)
+
+
+def test_extract_reference_features_cli_stacks_in_file_then_point_order(tmp_path):
+    """Reference scripts/extract_reference_features.py:50-59 semantics."""
+    from mermaid_classifier_amd.extract_reference_features import main, stack_feature_files
+    from mermaid_classifier_amd.spacer_shim import DataLocation, ImageFeatures, PointFeatures
+    files = []
+    for i, rows in enumerate(([[1, 2, 3], [4, 5, 6]], [[7, 8, 9]])):
+        pfs = [PointFeatures(r, r, [float(v) for v in row]) for r, row in enumerate(rows)]
+        p = tmp_path / f"i{i}.featurevector"
+        ImageFeatures(pfs, True, 3, len(pfs)).store(DataLocation("filesystem", str(p)))
+        files.append(str(p))
+    x = stack_feature_files(files)
+    assert x.dtype == np.float32 and x.tolist() == [[1, 2, 3], [4, 5, 6], [7, 8, 9]]
+    out = tmp_path / "ref.npy"
+    main(["--out", str(out)] + files)
+    assert np.array_equal(np.load(out), x)
+
+
+def test_check_extract_inputs():
+    from mermaid_classifier_amd.pipeline import check_extract_inputs
+    img = np.zeros((300, 400, 3), np.uint8)
+    check_extract_inputs(img, [(0, 0), (299, 399)])
+    with pytest.raises(ValueError, match="outside"):
+        check_extract_inputs(img, [(300, 0)])
+    with pytest.raises(ValueError, match="exceed"):
+        check_extract_inputs(np.zeros((200, 400, 3), np.uint8), [(1, 1)])
