@@ -13,7 +13,7 @@ struct GemmArgs {
     const float* bias;   // [n_chunks*16*nt] natural channel order, zero padded
     _Float16* Y;         // [M][N]
     int N;
-    int mt, nt, n_chunks;
+    int mt, nt, n_chunks, defer_gate;
     int epi;
     const float* gate;   // [patch][K] or null
     int HW;              // rows per patch

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 // EPI_LINEAR : y = acc+bias (+ residual)                       (project conv), optional SE gate on X
 // EPI_GAP    : out[patch][n] = mean over the patch's HW rows of silu(acc+bias)   (head conv + avgpool)
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI, bool GATE, bool RES, int UK>
+template <int MT, int NT, int EPI, bool GATE, bool RES, int UK, bool DG>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict__ X, int M, int K,
                                                       const _Float16* __restrict__ Wp, int KS32,
                                                       const float* __restrict__ bias,  // natural channel order, zero padded
@@ -197,7 +197,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
             wst[ps] = v;
         }
     };
-    auto load_x = [&](int bt, h8 (&dst)[UK][MT]) {
+    // DG (defer gate; used by the small-M 7x7 layers, which are latency- not occupancy-bound): activation
+    // fragments and their fp32 squeeze-excite gates are only LOADED in load_x; the multiply happens in
+    // apply_gate() right before the MFMAs that consume them, so the loads of batch bt+1 really overlap the
+    // MFMAs of batch bt.  !DG multiplies at load time (waits for the data, but keeps 8 fewer VGPRs per
+    // fragment alive, which is what the large-M layers want).
+    constexpr int GN = (GATE && DG) ? 2 : 1;
+    auto load_x = [&](int bt, h8 (&dst)[UK][MT], f4 (&g)[UK][MT][GN]) {
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
             const int k = (bt * UK + u) * 32 + q * 8;
@@ -207,9 +213,15 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
                 h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (kok && rok[i]) v = *reinterpret_cast<const h8*>(X + (size_t)row[i] * K + k);
                 if (GATE) {
+                    f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
                     if (kok && rok[i]) {
-                        const f4 g0 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k);
-                        const f4 g1 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k + 4);
+                        g0 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k);
+                        g1 = *reinterpret_cast<const f4*>(gate + (size_t)gpatch[i] * K + k + 4);
+                    }
+                    if (DG) {
+                        g[u][i][0] = g0;
+                        g[u][i][GN - 1] = g1;
+                    } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             v[j] = (_Float16)((float)v[j] * g0[j]);
@@ -221,20 +233,35 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
             }
         }
     };
+    auto apply_gate = [&](h8 (&x)[UK][MT], f4 (&g)[UK][MT][GN]) {
+        if (!(GATE && DG)) return;
+#pragma unroll
+        for (int u = 0; u < UK; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[u][i][j] = (_Float16)((float)x[u][i][j] * g[u][i][0][j]);
+                    x[u][i][4 + j] = (_Float16)((float)x[u][i][4 + j] * g[u][i][GN - 1][j]);
+                }
+    };
+    f4 gf[UK][MT][GN];
     load_w(0);
-    load_x(0, xf);
+    load_x(0, xf, gf);
     for (int bt = 0; bt < nbatch; ++bt) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int f = ps * 4 + wave;
             if (f < NFRAG) *reinterpret_cast<uint4*>(wlds + f * 512 + lane * 8) = wst[ps];
         }
+        apply_gate(xf, gf);
         __syncthreads();
         h8 xn[UK][MT];
+        f4 gn[UK][MT][GN];
         const bool more = bt + 1 < nbatch;
         if (more) {  // next batch's global loads fly during this batch's MFMAs
             load_w(bt + 1);
-            load_x(bt + 1, xn);
+            load_x(bt + 1, xn, gn);
         }
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
@@ -253,7 +280,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
 #pragma unroll
             for (int u = 0; u < UK; ++u)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) xf[u][i] = xn[u][i];
+                for (int i = 0; i < MT; ++i) {
+                    xf[u][i] = xn[u][i];
+#pragma unroll
+                    for (int e = 0; e < GN; ++e) gf[u][i][e] = gn[u][i][e];
+                }
         }
     }
     // epilogue: lane (m,q) holds channels cbase + 4t + j of pixel row[i]; acc already includes the bias
@@ -1040,15 +1071,14 @@ int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, co
     return 0;
 }
 
-template <int MT, int NT>
-static int launch_gemm_nt(const GemmArgs& a, hipStream_t st)
+template <int MT, int NT, int UK, bool DG>
+static int launch_gemm_uk(const GemmArgs& a, hipStream_t st)
 {
-    constexpr int UK = (MT * NT <= 4) ? 4 : 2;  // prefetch depth bounded by registers
     const int rows_per_wg = 64 * MT;
     dim3 grid((a.M + rows_per_wg - 1) / rows_per_wg, a.n_chunks, 1);
     dim3 block(256);
 #define GEMM_GO(EPI, GATE, RES)                                                                                    \
-    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, EPI, GATE, RES, UK>), grid, block, 0, st, a.X, a.M, a.K, a.Wp, a.Kp / 32,   \
+    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, EPI, GATE, RES, UK, DG>), grid, block, 0, st, a.X, a.M, a.K, a.Wp, a.Kp / 32,   \
                        a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw)
     if (a.epi == EPI_SILU) GEMM_GO(EPI_SILU, false, false);
     else if (a.epi == EPI_LINEAR) {
@@ -1062,11 +1092,22 @@ static int launch_gemm_nt(const GemmArgs& a, hipStream_t st)
     return 0;
 }
 
+template <int MT, int NT>
+static int launch_gemm_nt(const GemmArgs& a, hipStream_t st)
+{
+    // k-steps per LDS batch (UK) is bounded by registers; 7x7 project layers use the deferred-gate variant
+    if (MT * NT <= 4) {
+        if (MT == 1 && a.defer_gate) return launch_gemm_uk<MT, (MT * NT <= 4 ? NT : 1), 4, (MT == 1)>(a, st);
+        return launch_gemm_uk<MT, (MT * NT <= 4 ? NT : 1), 4, false>(a, st);
+    }
+    return launch_gemm_uk<MT, NT, 2, false>(a, st);
+}
+
 template <int NT>
 static int launch_gap_nt(const GemmArgs& a, hipStream_t st)
 {
     dim3 grid(a.M / a.HW, a.n_chunks, 1);
-    hipLaunchKernelGGL((pw_gemm_kernel<1, NT, EPI_GAP, false, false, (NT <= 4 ? 4 : 2)>), grid, dim3(256), 0, st, a.X, a.M, a.K, a.Wp,
+    hipLaunchKernelGGL((pw_gemm_kernel<1, NT, EPI_GAP, false, false, (NT <= 4 ? 4 : 2), false>), grid, dim3(256), 0, st, a.X, a.M, a.K, a.Wp,
                        a.Kp / 32, a.bias, a.Y, a.N, a.gate, a.HW, a.res, a.gap_out, a.inv_hw);
     LAUNCH_CHECK();
     return 0;
@@ -1212,12 +1253,12 @@ int launch_mbconv_a(const MbArgs& a, hipStream_t st)
     MB_CASE(5, 1, 2, 2, 3, 48, 14, 1)    // b4
     MB_CASE(3, 2, 2, 2, 2, 80, 14, 1)    // b5
     MB_CASE(3, 1, 2, 3, 2, 96, 14, 1)    // b6, b7
-    MB_CASE(5, 1, 2, 3, 2, 96, 14, 1)    // b8
-    MB_CASE(5, 1, 2, 4, 2, 96, 14, 1)    // b9, b10
-    MB_CASE(5, 2, 1, 4, 2, 96, 7, 1)     // b11
     MB_CASE(5, 1, 1, 6, 1, 192, 7, 1)    // b12-b14, one patch per workgroup
     MB_CASE(3, 1, 1, 6, 1, 192, 7, 1)    // b15
     MB_CASE(5, 1, 1, 6, 1, 96, 7, 2)     // b12-b14, two patches per workgroup
+    MB_CASE(5, 1, 2, 3, 2, 48, 14, 1)    // b8
+    MB_CASE(5, 1, 2, 4, 2, 48, 14, 1)    // b9, b10
+    MB_CASE(5, 2, 1, 4, 2, 48, 7, 1)     // b11
     MB_CASE(3, 1, 1, 6, 1, 96, 7, 2)     // b15
 #undef MB_CASE
     return -5;

@@ -120,8 +120,8 @@ struct BlockW {
 struct FuseCfg { int TH, TWo, CC, TW, PB, WLDS; };
 static const FuseCfg B0_FUSE[16] = {
     {0, 0, 0, 0, 1, 0},     {8, 8, 48, 2, 1, 0},    {14, 14, 48, 2, 1, 0},  {4, 14, 48, 2, 1, 0},   {14, 14, 48, 2, 1, 0},
-    {2, 14, 80, 2, 1, 0},   {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},
-    {14, 14, 96, 2, 1, 0},  {7, 7, 96, 1, 1, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},
+    {2, 14, 80, 2, 1, 0},   {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 48, 2, 1, 0},  {14, 14, 48, 2, 1, 0},
+    {14, 14, 48, 2, 1, 0},  {7, 7, 48, 1, 1, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},
     {7, 7, 96, 1, 2, 0}};
 
 struct Saved {
@@ -423,9 +423,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 B.f_wlds = fc.WLDS ? 1 : 0;
                 B.f_wfr_off = ppad * (fc.CC * 2 + 16);                       // E | [weight fragments] | taps+bias
                 B.f_wl_off = B.f_wfr_off + (B.f_wlds ? (fc.CC / 16) * B.f_ksteps * 1024 : 0);
-                B.f_red_off = 0;  // pool scratch aliases E
                 B.f_lds = B.f_wl_off + (B.d.k * B.d.k + 1) * fc.CC * 4;
-                if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wfr_off) B.f_lds = 1 << 30;
+                B.f_red_off = 0;  // pool scratch [PB][S][CC] aliases E when it fits, else gets its own space
+                if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wfr_off) { B.f_red_off = B.f_lds; B.f_lds += B.f_pb * B.f_S * fc.CC * 4; }
                 const int kp = 32 * B.f_ksteps;
                 if (B.f_lds <= (B.f_wlds ? 128 : 64) * 1024 && fc.TWo % B.f_tw == 0) {
                     std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
@@ -545,6 +545,7 @@ static int run_gemm(const PwLayer& L, const _Float16* X, int M, _Float16* Y, int
     a.nt = L.nt; a.n_chunks = L.n_chunks; a.epi = epi; a.gate = gate; a.HW = HW; a.res = res;
     a.gap_out = gap_out; a.inv_hw = (float)(1.0 / ((double)HW * LOG2E));  // GAP input is log2(e)-scaled
     a.mt = gemm_mt(L, M);
+    a.defer_gate = (gate && HW <= 49) ? 1 : 0;   // 7x7 layers: few workgroups, deep K -> overlap loads with MFMAs
     return launch_pw_gemm(a, st);
 }
 
