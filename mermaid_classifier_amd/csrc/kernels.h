@@ -51,6 +51,8 @@ struct MbArgs {
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
                 hipStream_t st);
+int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, const float* Wdw,
+                   const float* bdw, _Float16* out, float* pool_part, int B, hipStream_t st);
 int launch_pw_gemm(const GemmArgs& a, hipStream_t st);
 int launch_dwconv(const DwArgs& a, hipStream_t st);
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* WrP, const float* br,

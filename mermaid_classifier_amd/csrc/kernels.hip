@@ -1053,6 +1053,193 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused stem + block-0 depthwise: u8 patch -> [stem conv3x3s2 + bias + SiLU] -> LDS -> [depthwise 3x3 s1 +
+// bias + SiLU] -> fp16 NHWC (112x112x32) + squeeze-excite partial sums.  The 112x112x32 stem output (the
+// largest tensor of the net after the expanded ones) never goes to HBM.  Same two-phase structure as
+// mbconv_a_kernel: one workgroup = (patch, 16x16 output tile); phase 1 builds MFMA operands from the
+// staged u8 tile exactly like stem_conv_kernel (K packing and normalisation folding are shared).
+// ---------------------------------------------------------------------------------------------
+#define SD_T 16                       // output tile edge
+#define SD_WIN (SD_T + 2)             // stem window edge (halo 1)
+#define SD_IN (2 * SD_WIN + 1)        // input tile edge (37)
+#define SD_ROWH 128                   // halves per staged input row (123 used)
+#define SD_ES 80                      // bytes per E row: 32 ch * 2 + 16
+__global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict__ patches,  // [B][224][224][3]
+                                                      const _Float16* __restrict__ w,        // [32][32] stem (n, kslot)
+                                                      const float* __restrict__ bias,        // [32] stem
+                                                      const float* __restrict__ padval,      // [3]
+                                                      const float* __restrict__ Wdw,         // [9][32]
+                                                      const float* __restrict__ bdw,         // [32]
+                                                      _Float16* __restrict__ out,            // [B][112][112][32]
+                                                      float* __restrict__ pool_part)         // [B][49][32]
+{
+    __shared__ __attribute__((aligned(16))) _Float16 tile[SD_IN * SD_ROWH];                    // 8.3 KB
+    __shared__ __attribute__((aligned(16))) unsigned char E[((SD_WIN * SD_WIN + 15) / 16 * 16) * SD_ES];  // 26.9 KB
+    __shared__ __attribute__((aligned(16))) float wl[9 * 32];
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int oy0 = ty * SD_T, ox0 = tx * SD_T;
+    int wy0 = oy0 - 1, wy1 = oy0 + SD_T + 1, wx0 = ox0 - 1, wx1 = ox0 + SD_T + 1;
+    wy0 = wy0 < 0 ? 0 : wy0;
+    wx0 = wx0 < 0 ? 0 : wx0;
+    wy1 = wy1 > 112 ? 112 : wy1;
+    wx1 = wx1 > 112 ? 112 : wx1;
+    const int ww = wx1 - wx0, wh = wy1 - wy0;
+    const int P = wh * ww;
+    const unsigned wmagic = (65536u + ww - 1) / ww;
+    // ---- stage the input tile as exact fp16 (u8-128): rows 2*wy0 .. 2*wy1, cols from 2*(16tx-2) so that every
+    //      row segment starts on a dword (6*(16tx-2) bytes); 37 rows x 31 dwords (41 pixels), one dword per thread-step
+    const int icol0 = 2 * (ox0 - 2);                 // may be -4 for the leftmost tiles (those pixels are never used)
+    const int cshift = 2 * wx0 - icol0;              // staged column of the window's first input pixel (2 or 4)
+    {
+        const uint8_t* img = patches + (size_t)b * (224 * 224 * 3);
+        const int iy0 = 2 * wy0;
+        const int rows = 2 * wh + 1;
+        const float pv0 = padval[0], pv1 = padval[1], pv2 = padval[2];
+        for (int i = tid; i < rows * 31; i += 256) {
+            const int r = i / 31, d = i - r * 31;
+            const int iy = iy0 + r;
+            const int boff = icol0 * 3 + d * 4;      // byte offset in the image row (multiple of 4, may be negative)
+            uint32_t word = 0;
+            const bool row_ok = iy < 224;
+            if (row_ok && boff >= 0 && boff < 672) word = *reinterpret_cast<const uint32_t*>(img + (size_t)iy * 672 + boff);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int bb = d * 4 + e;             // byte inside the staged row (0..123)
+                const int pix = bb / 3, c = bb - pix * 3;
+                const int col = icol0 + pix;
+                float v;
+                if (row_ok && col >= 0 && col < 224) v = (float)((word >> (8 * e)) & 0xffu) - 128.0f;
+                else v = (c == 0) ? pv0 : (c == 1 ? pv1 : pv2);
+                if (bb < 123) tile[r * SD_ROWH + bb] = (_Float16)v;
+            }
+        }
+        for (int i = tid; i < 9 * 32; i += 256) wl[i] = Wdw[i];
+    }
+    __syncthreads();
+    // ---- phase 1: stem conv on the window -> E[p][32] ----
+    {
+        h8 wf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
+        f4 bsv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bsv[t] = *reinterpret_cast<const f4*>(bias + q * 8 + t * 4);
+        const int MTn = (P + 15) >> 4;
+        for (int mt = wave; mt < MTn; mt += 4) {
+            const int p = mt * 16 + m;
+            const bool ok = p < P;
+            const int py = ok ? (int)(((unsigned)p * wmagic) >> 16) : 0, px = ok ? p - py * ww : 0;
+            h8 a;
+            if (q < 3) {
+                // 8 consecutive halves starting on a dword boundary (6*px + 3*cshift is even): four 32-bit LDS reads
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(tile + (2 * py + q) * SD_ROWH + 3 * cshift + 6 * px);
+                union { uint32_t u[4]; h8 v; } cv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv.u[j] = src[j];
+                a = cv.v;
+            } else {
+                union { uint32_t u[4]; h8 v; } cv;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    cv.u[j] = *reinterpret_cast<const uint32_t*>(tile + (2 * py + j) * SD_ROWH + 3 * cshift + 6 * px + 8) & 0xffffu;
+                cv.u[3] = 0u;
+                // slots 0,1,2 take the three values; repack: (v0,v1),(v2,0),(0,0),(0,0)
+                cv.u[0] = cv.u[0] | (cv.u[1] << 16);
+                cv.u[1] = cv.u[2];
+                cv.u[2] = 0u;
+                a = cv.v;
+            }
+            h8 o;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], a, bsv[t], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_scaled(acc[j]);
+            }
+            if (ok) *reinterpret_cast<h8*>(E + p * SD_ES + q * 16) = o;   // lane (m,q): channels 8q..8q+7
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: depthwise 3x3 stride 1 from E; thread = (4 channel groups) x (64 strips of 4 pixels) ----
+    const int cg = tid & 3, s = tid >> 2;
+    const int oyl = s >> 2, oxl = (s & 3) * 4;
+    const int oy = oy0 + oyl, ox = ox0 + oxl;
+    float bs[8];
+    {
+        const f4 b0 = *reinterpret_cast<const f4*>(bdw + cg * 8);
+        const f4 b1 = *reinterpret_cast<const f4*>(bdw + cg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
+    }
+    float acc[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy - 1 + ky;
+        if (iy < 0 || iy >= 112) continue;
+        const int rbase = (iy - wy0) * ww - wx0;
+        float wk[3][8];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const f4 w0 = *reinterpret_cast<const f4*>(wl + (ky * 3 + kx) * 32 + cg * 8);
+            const f4 w1 = *reinterpret_cast<const f4*>(wl + (ky * 3 + kx) * 32 + cg * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
+        }
+#pragma unroll
+        for (int xr = 0; xr < 6; ++xr) {
+            const int ix = ox - 1 + xr;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (ix >= 0 && ix < 112) v = *reinterpret_cast<const uint4*>(E + (rbase + ix) * SD_ES + cg * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kx = xr - t;
+                if (kx >= 0 && kx < 3) {
+                    acc[t][0] = fma_mix_lo(v.x, wk[kx][0], acc[t][0]);
+                    acc[t][1] = fma_mix_hi(v.x, wk[kx][1], acc[t][1]);
+                    acc[t][2] = fma_mix_lo(v.y, wk[kx][2], acc[t][2]);
+                    acc[t][3] = fma_mix_hi(v.y, wk[kx][3], acc[t][3]);
+                    acc[t][4] = fma_mix_lo(v.z, wk[kx][4], acc[t][4]);
+                    acc[t][5] = fma_mix_hi(v.z, wk[kx][5], acc[t][5]);
+                    acc[t][6] = fma_mix_lo(v.w, wk[kx][6], acc[t][6]);
+                    acc[t][7] = fma_mix_hi(v.w, wk[kx][7], acc[t][7]);
+                }
+            }
+        }
+    }
+    float pooled[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pooled[j] = 0.f;
+    _Float16* outb = out + (size_t)b * 112 * 112 * 32 + cg * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = silu_scaled(acc[t][j]);
+            pooled[j] += y;
+            o[j] = (_Float16)y;
+        }
+        *reinterpret_cast<h8*>(outb + ((size_t)oy * 112 + ox + t) * 32) = o;
+    }
+    __syncthreads();  // E is free: reuse it for the pool scratch [64 strips][32]
+    float* red = reinterpret_cast<float*>(E);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[s * 32 + cg * 8 + j] = pooled[j];
+    __syncthreads();
+    if (tid < 32) {
+        float sum = 0.f;
+        for (int ss = 0; ss < 64; ++ss) sum += red[ss * 32 + tid];
+        pool_part[((size_t)b * 49 + ty * 7 + tx) * 32 + tid] = sum;
+    }
+}
+
 // =============================================================================================
 // Host-side launchers (plain C++ signatures declared in kernels.h)
 // =============================================================================================
@@ -1232,6 +1419,14 @@ static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
                            st, a.X, a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo,
                            a.pad, a.TH, a.tiles_x, a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off);
     } else {
+        static bool attr_done2 = false;
+        if (!attr_done2 && a.lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_done2 = true;
+        }
         hipLaunchKernelGGL((mbconv_a_kernel<KS, ST, TW, KSTEPS, NPAIR, CC, TWO, PB, false>), grid, dim3(256), a.lds_bytes,
                            st, a.X, a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo,
                            a.pad, a.TH, a.tiles_x, a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off);
@@ -1262,4 +1457,12 @@ int launch_mbconv_a(const MbArgs& a, hipStream_t st)
     MB_CASE(3, 1, 1, 6, 1, 96, 7, 2)     // b15
 #undef MB_CASE
     return -5;
+}
+
+int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, const float* Wdw,
+                   const float* bdw, _Float16* out, float* pool_part, int B, hipStream_t st)
+{
+    hipLaunchKernelGGL(stem_dw_kernel, dim3(7, 7, B), dim3(256), 0, st, patches, w, bias, padval, Wdw, bdw, out, pool_part);
+    LAUNCH_CHECK();
+    return 0;
 }

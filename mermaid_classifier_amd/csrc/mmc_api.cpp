@@ -153,7 +153,7 @@ struct mmc_backbone {
     float* out_stage = nullptr;
     size_t ws_bytes = 0;
     std::vector<void*> allocs;
-    bool keep = false;
+    bool keep = false, fuse_stem = false;
     std::map<std::string, Saved> saved;
     int last_n = 0;
 };
@@ -319,6 +319,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     // ---- blocks ----
     const char* fuse_env = getenv("MMC_FUSE");
     const bool fuse_enabled = !(fuse_env && fuse_env[0] == '0');
+    bb->fuse_stem = fuse_enabled;
     int H = IMG / 2;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
     int max_c = 0;
@@ -427,7 +428,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 B.f_red_off = 0;  // pool scratch [PB][S][CC] aliases E when it fits, else gets its own space
                 if (B.f_pb * B.f_S * fc.CC * 4 > B.f_wfr_off) { B.f_red_off = B.f_lds; B.f_lds += B.f_pb * B.f_S * fc.CC * 4; }
                 const int kp = 32 * B.f_ksteps;
-                if (B.f_lds <= (B.f_wlds ? 128 : 64) * 1024 && fc.TWo % B.f_tw == 0) {
+                if (B.f_lds <= 128 * 1024 && fc.TWo % B.f_tw == 0) {
                     std::vector<_Float16> wn((size_t)B.ce * kp, (_Float16)0.0f);
                     for (int c = 0; c < B.ce; ++c)
                         for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)(float)(exp_w_host[(size_t)c * B.d.cin + k] * LOG2E);
@@ -449,6 +450,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         if ((size_t)B.Ho * B.Ho * B.ce > max_dw) max_dw = (size_t)B.Ho * B.Ho * B.ce;
         if ((size_t)B.Ho * B.Ho * B.d.cout > max_act) max_act = (size_t)B.Ho * B.Ho * B.d.cout;
         if ((size_t)B.parts * B.ce > max_pool) max_pool = (size_t)B.parts * B.ce;
+        if (i == 0 && (size_t)49 * B.ce > max_pool) max_pool = (size_t)49 * B.ce;
         if (B.ce > max_c) max_c = B.ce;
         H = B.Ho;
     }
@@ -570,13 +572,20 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
     char nm[64];
     _Float16* x = ws.act0;
     _Float16* y = ws.act1;
-    STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
-    if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
+    const bool stem_fused = bb->fuse_stem;   // then the stem tensor never exists in HBM (no "stem" activation to keep)
+    if (!stem_fused) {
+        STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
+        if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
+    }
     for (int i = 0; i < 16; ++i) {
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
-        if (B.fused) {
+        if (i == 0 && stem_fused) {
+            STEP("stem+b0.dw", "stem_dw", launch_stem_dw(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, B.dw_w, B.dw_b,
+                                                          ws.dwbuf, ws.pool_part, n, st));
+            nparts = 49;
+        } else if (B.fused) {
             MbArgs a{};
             a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = ws.dwbuf;
             a.pool_part = ws.pool_part; a.B = n; a.H = B.H; a.W = B.H; a.Cin = B.d.cin; a.Ce = B.ce; a.Ho = B.Ho;

@@ -25,6 +25,9 @@ def b0_launches(batch: int) -> List[Launch]:
     h = 112
     out.append(Launch("stem", "stem", batch * (224 * 224 * 3 + h * h * 32 * 2) + 32 * 32 * 2,
                       2 * batch * h * h * 32 * 27))
+    # fused alternative of stem + block-0 depthwise (stem_dw_kernel): the stem tensor never reaches HBM
+    out.append(Launch("stem+b0.dw", "stem_dw", batch * (224 * 224 * 3 + h * h * 32 * 2) + 32 * 32 * 2 + 9 * 32 * 4,
+                      2 * batch * h * h * 32 * (27 + 9)))
     for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
         ce = cin * e
         cs = max(1, cin // 4)
@@ -53,7 +56,7 @@ def totals(batch: int, launched=None) -> Dict[str, float]:
         names = set(launched)
         ls = [l for l in ls if l.name in names]
     else:
-        ls = [l for l in ls if l.kind != "mbconv"]
+        ls = [l for l in ls if l.kind not in ("mbconv", "stem_dw")]
     return {"bytes": float(sum(l.bytes for l in ls)), "flops": float(sum(l.flops for l in ls)),
             "bytes_per_patch": sum(l.bytes for l in ls) / batch, "flops_per_patch": sum(l.flops for l in ls) / batch}
 
