@@ -49,6 +49,7 @@ struct MbArgs {
 };
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
+int launch_mbconv_d(const MbArgs& a, hipStream_t st);   // dot2 depthwise variant (pair-interleaved LDS tile)
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
                 hipStream_t st);
 int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, const float* Wdw,

@@ -1054,6 +1054,249 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// mbconv_d_kernel: the fused MBConv front half with the depthwise taps on v_dot2c_f32_f16.
+// Same decomposition as mbconv_a_kernel (patch x output tile x chunk of CC channels, phase 1 = expand
+// GEMM + SiLU into LDS, phase 2 = depthwise + SiLU + pool partials), but the expanded tile is stored
+// PAIR-INTERLEAVED: E2[row][xp][c] is one dword = (E[row][2xp][c], E[row][2xp+1][c]) -- two horizontally
+// adjacent pixels of one channel, pairs aligned to even absolute x.  One v_dot2c then does TWO taps
+// (fp16 x fp16 products, fp32 accumulate): 3 instead of 5 per kernel row for k=5, 2 instead of 3 for k=3,
+// and since E2 holds real zeros outside the image no tap needs a bounds test.
+//   * phase 1 runs the MFMA un-swapped (positions = A operand rows, channels = B operand columns) so a
+//     lane ends up with 4 CONSECUTIVE positions of ONE channel = two ready-made pairs (two ds_write_b32).
+//   * a thread owns 8 channels x 2 adjacent outputs (x even); for each kernel row it loads NP pairs
+//     (32 B each) and the row's tap-pair weights (fp16 pairs built once per workgroup in LDS).
+// Positions enumerate rows [wy0,wy1) x pair columns [xp0,xp1) x 2; a position with x >= W (odd W only)
+// is written as zero.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+template <int KS, int ST>
+struct DwPairs {
+    static constexpr int PAD = (ST == 1) ? (KS - 1) / 2 : (KS == 3 ? 0 : 1);   // TF-same "before" pad
+    static constexpr int OFF = PAD & 1;                                           // first tap's offset in its pair
+    static constexpr int NP = (OFF + ST + KS + 1) / 2;                            // pairs a 2-output strip touches
+};
+
+template <int KS, int ST, int KSTEPS, int NPAIR, int CC, int TWO, int PB>
+__global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
+                                                       const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
+                                                       const float* __restrict__ bexp,     // [Ce]
+                                                       const float* __restrict__ Wdw,      // [KS*KS][Ce] fp32
+                                                       const float* __restrict__ bdw,      // [Ce]
+                                                       _Float16* __restrict__ out,         // [B][Ho][Wo][Ce]
+                                                       float* __restrict__ pool_part,      // [B][ntiles][Ce]
+                                                       int H, int W, int Cin, int Ce, int Ho, int Wo, int TH,
+                                                       int tiles_x, int wl_off, int red_off, int nB)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using DP = DwPairs<KS, ST>;
+    constexpr int PAD = DP::PAD, OFF = DP::OFF, NP = DP::NP;
+    constexpr int Kp = 32 * KSTEPS;
+    constexpr int CCG = CC / 8, S = 256 / CCG, NTC = CC / 16;
+    constexpr int SPR = (TWO + 1) / 2;                     // 2-output strips per tile row
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z * PB;
+    const int nb = (nB - b) < PB ? (nB - b) : PB;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TWO;
+    int wy0 = oy0 * ST - PAD, wy1 = (oy0 + TH - 1) * ST - PAD + KS;
+    int wx0 = ox0 * ST - PAD, wx1 = (ox0 + TWO - 1) * ST - PAD + KS;
+    wy0 = wy0 < 0 ? 0 : wy0;
+    wx0 = wx0 < 0 ? 0 : wx0;
+    wy1 = wy1 > H ? H : wy1;
+    wx1 = wx1 > W ? W : wx1;
+    const int xp0 = wx0 >> 1, xp1 = (wx1 + 1) >> 1;       // pair columns [xp0, xp1)
+    const int npx = xp1 - xp0, rowlen = 2 * npx;
+    const int P1 = (wy1 - wy0) * rowlen;                  // positions of one patch's window (even)
+    const int P = (PB > 1 ? nb : 1) * P1;
+    const unsigned rmagic = (65536u + rowlen - 1) / rowlen;
+    uint32_t* E2 = reinterpret_cast<uint32_t*>(smem);      // [P/2][CC] pair dwords
+    uint32_t* wl2 = reinterpret_cast<uint32_t*>(smem + wl_off);   // [KS][2][NP][CC] tap-pair weights (fp16 x2)
+    float* bl = reinterpret_cast<float*>(wl2 + KS * 2 * NP * CC); // expand bias [CC]
+    float* red = reinterpret_cast<float*>(smem + red_off);
+    // ---------------- phase 0: input fragments, tap-pair weights, bias ----------------
+    int p[NPAIR][2];
+    h8 xf[NPAIR][2][KSTEPS];
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pp = ((pr * 4 + wave) * 2 + i) * 16 + m;
+            p[pr][i] = pp;
+            bool ok = pp < P;
+            int pb = 0, pl = pp;
+            if (PB > 1) { pb = pp >= P1 ? (pp >= 2 * P1 ? (pp >= 3 * P1 ? 3 : 2) : 1) : 0; pl = pp - pb * P1; }
+            const int py = (int)(((unsigned)pl * rmagic) >> 16), pxx = pl - py * rowlen;
+            const int ix = 2 * xp0 + pxx;
+            ok = ok && ix < W;
+            const _Float16* xp = X + (((size_t)(b + pb) * H + wy0 + py) * W + (ok ? ix : 0)) * Cin + q * 8;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok && ks * 32 + q * 8 < Cin) v = *reinterpret_cast<const h8*>(xp + ks * 32);
+                xf[pr][i][ks] = v;
+            }
+        }
+    for (int i = tid; i < KS * 2 * NP * CC; i += 256) {
+        const int c = i % CC, r = i / CC;
+        const int ip = r % NP, t = (r / NP) % 2, ky = r / (2 * NP);
+        const int kx0 = 2 * ip - OFF - t * ST, kx1 = kx0 + 1;
+        h2 w;
+        w[0] = (kx0 >= 0 && kx0 < KS) ? (_Float16)Wdw[(size_t)(ky * KS + kx0) * Ce + chunk * CC + c] : (_Float16)0.0f;
+        w[1] = (kx1 >= 0 && kx1 < KS) ? (_Float16)Wdw[(size_t)(ky * KS + kx1) * Ce + chunk * CC + c] : (_Float16)0.0f;
+        wl2[i] = *reinterpret_cast<uint32_t*>(&w);
+    }
+    if (tid < CC) bl[tid] = bexp[chunk * CC + tid];
+    __syncthreads();
+    // ---------------- phase 1: expand GEMM (un-swapped) into pair-interleaved LDS ----------------
+    {
+        const _Float16* wbase = Wexp + ((size_t)chunk * CC + m) * Kp + q * 8;
+        h8 wn[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) wn[ks] = *reinterpret_cast<const h8*>(wbase + ks * 32);
+        for (int t = 0; t < NTC; ++t) {
+            h8 wc[KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) wc[ks] = wn[ks];
+            if (t + 1 < NTC) {
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks)
+                    wn[ks] = *reinterpret_cast<const h8*>(wbase + (size_t)(t + 1) * 16 * Kp + ks * 32);
+            }
+            const float bv = bl[t * 16 + m];   // this lane's channel: bias = accumulator init
+#pragma unroll
+            for (int pr = 0; pr < NPAIR; ++pr) {
+                const int pbase = ((pr * 4 + wave) * 2) * 16;
+                if (pbase >= P) continue;  // wave-uniform
+                f4 a0 = {bv, bv, bv, bv}, a1 = a0;
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[pr][0][ks], wc[ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[pr][1][ks], wc[ks], a1, 0, 0, 0);
+                }
+                // lane (m = channel, q): positions pbase + 4q + j  (fragment 0) and pbase + 16 + 4q + j (fragment 1)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const f4 a = f ? a1 : a0;
+                    const int pq = pbase + f * 16 + 4 * q;     // first of this lane's 4 positions (multiple of 4)
+                    if (pq >= P) continue;
+                    int pl = pq;
+                    if (PB > 1) { const int pb = pq >= P1 ? (pq >= 2 * P1 ? (pq >= 3 * P1 ? 3 : 2) : 1) : 0; pl = pq - pb * P1; }
+                    h2 v0, v1;
+                    v0[0] = (_Float16)silu_scaled(a[0]);
+                    v0[1] = (_Float16)silu_scaled(a[1]);
+                    v1[0] = (_Float16)silu_scaled(a[2]);
+                    v1[1] = (_Float16)silu_scaled(a[3]);
+                    if (W & 1) {   // odd image width: the pad pixel of the last pair of every row is a real zero
+                        const int py = (int)(((unsigned)pl * rmagic) >> 16), pxx = pl - py * rowlen;
+                        if (2 * xp0 + pxx + 1 >= W) v0[1] = (_Float16)0.0f;
+                        const int pl2 = pl + 2;
+                        const int py2 = (int)(((unsigned)pl2 * rmagic) >> 16), pxx2 = pl2 - py2 * rowlen;
+                        if (2 * xp0 + pxx2 + 1 >= W) v1[1] = (_Float16)0.0f;
+                    }
+                    uint32_t* dst = E2 + (size_t)(pq >> 1) * CC + t * 16 + m;
+                    dst[0] = *reinterpret_cast<uint32_t*>(&v0);
+                    if (pq + 2 < P) dst[CC] = *reinterpret_cast<uint32_t*>(&v1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------------- phase 2: depthwise on v_dot2c ----------------
+    const bool active = tid < CCG * S;
+    const int cg = tid % CCG, s = tid / CCG;
+    const int cglob = chunk * CC + cg * 8;
+    const int nstrips = TH * SPR;
+    float pooled[PB][8];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pooled[pb][j] = 0.f;
+    if (active) {
+        float bs[8];
+        {
+            const f4 b0 = *reinterpret_cast<const f4*>(bdw + cglob);
+            const f4 b1 = *reinterpret_cast<const f4*>(bdw + cglob + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
+        }
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb) {
+            if (pb >= nb) break;
+            _Float16* outb = out + (size_t)(b + pb) * Ho * Wo * Ce + cglob;
+            const int ebase = pb * (P1 >> 1);   // first pair of this patch
+            for (int strip = s; strip < nstrips; strip += S) {
+                const int oyl = strip / SPR;
+                const int oy = oy0 + oyl, ox = ox0 + (strip - oyl * SPR) * 2;   // ox even
+                float acc[2][8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
+                const int fp = (ox * ST - PAD - OFF) / 2 - xp0;   // first pair column (window-relative; may be < 0)
+#pragma unroll 1
+                for (int ky = 0; ky < KS; ++ky) {
+                    const int iy = oy * ST - PAD + ky;
+                    if (iy < 0 || iy >= H) continue;
+                    const uint32_t* erow = E2 + (size_t)(ebase + (iy - wy0) * npx) * CC + cg * 8;
+                    const uint32_t* wrow = wl2 + (size_t)ky * 2 * NP * CC + cg * 8;
+#pragma unroll
+                    for (int ip = 0; ip < NP; ++ip) {
+                        const int xpc = fp + ip;
+                        if (xpc < 0 || xpc >= npx) continue;   // whole pair outside the image: contributes zero
+                        const uint4 d0 = *reinterpret_cast<const uint4*>(erow + (size_t)xpc * CC);
+                        const uint4 d1 = *reinterpret_cast<const uint4*>(erow + (size_t)xpc * CC + 4);
+                        const uint32_t dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            constexpr int dummy = 0;
+                            (void)dummy;
+                            const int kx0 = 2 * ip - OFF - t * ST;
+                            if (kx0 + 1 < 0 || kx0 >= KS) continue;   // compile-time: this pair carries no tap of output t
+                            const uint4 w0 = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * NP + ip) * CC);
+                            const uint4 w1 = *reinterpret_cast<const uint4*>(wrow + (size_t)(t * NP + ip) * CC + 4);
+                            const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                acc[t][j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&dv[j]),
+                                                                   *reinterpret_cast<const h2*>(&wv[j]), acc[t][j], false);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (ox + t >= ox0 + TWO) continue;   // odd tile width: second output of the last strip does not exist
+                    h8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = silu_scaled(acc[t][j]);
+                        pooled[pb][j] += y;
+                        o[j] = (_Float16)y;
+                    }
+                    *reinterpret_cast<h8*>(outb + ((size_t)oy * Wo + ox + t) * Ce) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[(pb * S + s) * CC + cg * 8 + j] = pooled[pb][j];
+    }
+    __syncthreads();
+    for (int e = tid; e < PB * CC; e += 256) {
+        const int pb = e / CC, c = e - pb * CC;
+        if (pb >= nb) continue;
+        float sum = 0.f;
+        for (int ss = 0; ss < S; ++ss) sum += red[(pb * S + ss) * CC + c];
+        pool_part[((size_t)(b + pb) * gridDim.x + tile) * Ce + chunk * CC + c] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused stem + block-0 depthwise: u8 patch -> [stem conv3x3s2 + bias + SiLU] -> LDS -> [depthwise 3x3 s1 +
 // bias + SiLU] -> fp16 NHWC (112x112x32) + squeeze-excite partial sums.  The 112x112x32 stem output (the
 // largest tensor of the net after the expanded ones) never goes to HBM.  Same two-phase structure as
@@ -1465,4 +1708,36 @@ int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias,
     hipLaunchKernelGGL(stem_dw_kernel, dim3(7, 7, B), dim3(256), 0, st, patches, w, bias, padval, Wdw, bdw, out, pool_part);
     LAUNCH_CHECK();
     return 0;
+}
+
+template <int KS, int ST, int KSTEPS, int NPAIR, int CC, int TWO, int PB>
+static int launch_mbconv_d_t(const MbArgs& a, hipStream_t st)
+{
+    dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, (a.B + PB - 1) / PB);
+    static bool attr_done = false;
+    if (!attr_done && a.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_d_kernel<KS, ST, KSTEPS, NPAIR, CC, TWO, PB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mbconv_d_kernel<KS, ST, KSTEPS, NPAIR, CC, TWO, PB>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp,
+                       a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.TH, a.tiles_x,
+                       a.wl_off, a.red_off, a.B);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mbconv_d(const MbArgs& a, hipStream_t st)
+{
+    if (a.pb > 1 && (a.tiles_x * a.tiles_y != 1 || a.TH != a.Ho || a.TWo != a.Wo)) return -8;
+#define MD_CASE(KS_, ST_, KSTEPS_, NPAIR_, CC_, TWO_, PB_)                                                   \
+    if (a.ks == KS_ && a.stride == ST_ && a.ksteps == KSTEPS_ && a.npair == NPAIR_ && a.CC == CC_ &&         \
+        a.TWo == TWO_ && a.pb == PB_)                                                                        \
+        return launch_mbconv_d_t<KS_, ST_, KSTEPS_, NPAIR_, CC_, TWO_, PB_>(a, st);
+    MD_CASE(5, 1, 2, 3, 48, 14, 1)    // b4
+    MD_CASE(5, 1, 4, 2, 48, 14, 1)    // b9, b10
+    MD_CASE(5, 1, 6, 1, 96, 7, 2)     // b12-b14
+#undef MD_CASE
+    return -5;
 }

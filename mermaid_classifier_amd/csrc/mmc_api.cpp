@@ -111,6 +111,9 @@ struct BlockW {
     _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
     int f_TH = 0, f_TWo = 0, f_CC = 0, f_tw = 0, f_ksteps = 0, f_CCG = 0, f_S = 0, f_tiles_x = 0, f_tiles_y = 0,
         f_red_off = 0, f_lds = 0, f_npair = 0, f_wl_off = 0, f_pb = 1, f_wlds = 0, f_wfr_off = 0;
+    // geometry of the dot2 variant (mbconv_d_kernel): pair-aligned windows are a little wider
+    bool use_d = false;
+    int d_npair = 0, d_wl_off = 0, d_red_off = 0, d_lds = 0;
     _Float16* exp_frag = nullptr;  // expand weights in MFMA fragment order
 };
 
@@ -319,6 +322,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     // ---- blocks ----
     const char* fuse_env = getenv("MMC_FUSE");
     const bool fuse_enabled = !(fuse_env && fuse_env[0] == '0');
+    const char* dot2_env = getenv("MMC_MB_DOT2");
+    const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
     bb->fuse_stem = fuse_enabled;
     int H = IMG / 2;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
@@ -441,6 +446,28 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                         TRY_OR_FREE(dev_upload(bb, &B.exp_frag, wf));
                     }
                     B.fused = true;
+                    // dot2 depthwise variant: only where it measured faster (5x5 stride-1 blocks; MI355X, batch 128/256)
+                    static const bool B0_DOT2[16] = {0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 1, 1, 1, 0};
+                    if (dot2_enabled && (B0_DOT2[i] || (dot2_env && dot2_env[0] == '2'))) {
+                        // window of mbconv_d_kernel: rows as above, columns widened to whole pixel pairs (even absolute x)
+                        const int padb = B.pad;
+                        int rowlen = 0;
+                        for (int tx = 0; tx < B.f_tiles_x; ++tx) {
+                            int x0 = tx * fc.TWo * B.d.s - padb, x1 = (tx * fc.TWo + fc.TWo - 1) * B.d.s - padb + B.d.k;
+                            x0 = x0 < 0 ? 0 : x0;
+                            x1 = x1 > H ? H : x1;
+                            const int rl = 2 * (((x1 + 1) >> 1) - (x0 >> 1));
+                            if (rl > rowlen) rowlen = rl;
+                        }
+                        const int dpad = (B.f_pb * wh * rowlen + 15) / 16 * 16;
+                        const int np = (B.pad % 2 + B.d.s + B.d.k + 1) / 2;
+                        B.d_npair = (dpad / 16 + 7) / 8;
+                        B.d_wl_off = dpad * fc.CC * 2;
+                        B.d_lds = B.d_wl_off + B.d.k * 2 * np * fc.CC * 4 + fc.CC * 4;
+                        B.d_red_off = 0;
+                        if (B.f_pb * B.f_S * fc.CC * 4 > B.d_wl_off) { B.d_red_off = B.d_lds; B.d_lds += B.f_pb * B.f_S * fc.CC * 4; }
+                        B.use_d = B.d_lds <= 128 * 1024;
+                    }
                     const size_t pp = (size_t)B.f_tiles_x * B.f_tiles_y * B.ce;
                     if (pp > max_pool) max_pool = pp;
                 }
@@ -596,8 +623,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             nparts = B.f_tiles_x * B.f_tiles_y;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char fl[48];
-            snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb, a.wlds);
-            STEP(nm, fl, launch_mbconv_a(a, st));
+            if (B.use_d) {
+                a.npair = B.d_npair; a.wl_off = B.d_wl_off; a.red_off = B.d_red_off; a.lds_bytes = B.d_lds;
+                snprintf(fl, sizeof fl, "mbconv_d<%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.ksteps, a.npair, a.CC, a.TWo, a.pb);
+                STEP(nm, fl, launch_mbconv_d(a, st));
+            } else {
+                snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb, a.wlds);
+                STEP(nm, fl, launch_mbconv_a(a, st));
+            }
         } else {
             const _Float16* dw_in = x;
             if (B.has_expand) {
