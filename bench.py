@@ -161,8 +161,21 @@ def main():
         dom, (ms, launches, nbytes) = max(per_kernel.items(), key=lambda kv: kv[1][0])
         achieved = nbytes / (ms * 1e-3) / 1e9
         tot = schedule.totals(BATCH, launched)
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profiles.py), if present
+        traffic = None
+        try:
+            pmc = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
+            table = json.loads(pmc.read_text())
+            key = dom.split("<")[0]
+            hits = [v for k, v in table.items() if k.split("<")[0].replace("_kernel", "") == key.replace("_kernel", "")
+                    and (("<" not in dom) or k.split("<")[1].split(">")[0].split(",")[:3] == dom.split("<")[1].split(">")[0].split(",")[:3])]
+            if hits:
+                traffic = sum(h["read_bytes_per_launch"] + h["write_bytes_per_launch"] for h in hits) / len(hits)
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": schedule.HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / schedule.HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / schedule.HBM_PEAK_GBS, "traffic": traffic,
                     "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
                     "patches_per_launch": sub,
                     "alg_bytes_per_launch": nbytes / launches,

@@ -24,7 +24,9 @@ def short(name):
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    rows = list(csv.DictReader(open(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0])))
+    import os
+    latest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+    rows = list(csv.DictReader(open(latest(f"{stats_dir}/*/*kernel_stats.csv"))))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     out = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
            "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 "
@@ -39,7 +41,7 @@ def main():
     if len(sys.argv) >= 5:
         def load(d, counter):
             acc = collections.defaultdict(lambda: [0.0, 0])
-            for r in csv.DictReader(open(glob.glob(f"{d}/*/*counter_collection.csv")[0])):
+            for r in csv.DictReader(open(latest(f"{d}/*/*counter_collection.csv"))):
                 if r["Counter_Name"] == counter:
                     k = short(r["Kernel_Name"])
                     acc[k][0] += float(r["Counter_Value"])
@@ -55,6 +57,11 @@ def main():
             if f[k][0] / 1024 < 1 and w[k][0] / 1024 < 1:
                 continue
             out.append(f"| `{k}` | {f[k][1]} | {2 * f[k][0] / f[k][1] / 1024:.1f} | {w[k][0] / max(1, w[k][1]) / 1024:.1f} |")
+    if len(sys.argv) >= 5:
+        import json
+        traffic = {k: {"read_bytes_per_launch": 2 * f[k][0] / f[k][1] * 1024, "write_bytes_per_launch": w[k][0] / max(1, w[k][1]) * 1024,
+                       "launches": f[k][1]} for k in f}
+        (ROOT / "profiles" / f"{tag}_pmc_traffic.json").write_text(json.dumps(traffic, indent=1))
     dst = ROOT / "profiles" / f"{tag}_rocprof_summary.md"
     dst.write_text("\n".join(out) + "\n")
     print(dst)
