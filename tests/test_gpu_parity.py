@@ -172,3 +172,31 @@ def test_cross_image_batching_matches_per_image_oracle(backbone, oracle_net):
     assert feats.npoints == 3 and np.allclose(feats.get_array((150, 200)), got[0][1])
     with pytest.raises(ValueError):
         ex.extract_images(images[:1], [[(400, 1)]])
+
+
+def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone):
+    """BASELINE configs[1] size (256 patches per pass, both lanes, every CU busy): properties that do not need
+    the oracle at this size -- rows depend only on their own patch (duplicates and permutations are bitwise
+    consistent), run-to-run determinism, and the golden rows are reproduced inside the big batch."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    base = np.concatenate([ref.natural_patches(8, seed=7), ref.synthetic_patches(8, seed=42), ref.natural_patches(16, seed=13)])
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, len(base), size=256)
+    idx[:32] = np.arange(32)
+    p = base[idx]
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=256)
+    f = bb.extract(p)
+    assert np.isfinite(f).all() and f.shape == (256, 1280)
+    for i in range(32, 256):                                  # duplicates of a patch give the duplicate's exact bits
+        assert np.array_equal(f[i], f[idx[i]])
+    perm = rng.permutation(256)
+    assert np.array_equal(bb.extract(p[perm]), f[perm])       # permutation equivariance, bitwise
+    assert np.array_equal(bb.extract(p), f)                   # deterministic
+    assert rel_l2(f[:8], golden_backbone["natural8"]).max() < TOL_NATURAL
+    assert cosine(f[8:16], golden_backbone["noise8"]).min() >= COS_GATE
+    # 300 > max_batch: internal chunking + ragged lanes give the same rows
+    q = np.concatenate([p, p[:44]])
+    g = bb.extract(q)
+    assert np.array_equal(g[:256], f) and np.array_equal(g[256:], f[:44])
+    bb.close()
