@@ -48,6 +48,26 @@ struct MbArgs {
     int wl_off, red_off, lds_bytes, wlds, wfr_off;
 };
 
+// One 7x7 MBConv block (192 -> 1152 -> 192, k5 s1, skip) packed for tail7_kernel
+struct TailBlock {
+    const _Float16* wexp;   // [72][6][64][8] expand weights, MFMA fragment order
+    const float* bexp;      // [1152]
+    const uint32_t* dwp;    // [30][1152] depthwise tap pairs (fp16 x2): index (ky*2 + t)*3 + ip
+    const float* bdw;       // [1152]
+    const float *wrp, *br, *wep, *be;   // squeeze-excite, as se_fused_kernel
+    const _Float16* wproj;  // [12][36][64][8] project weights, MFMA fragment order
+    const float* bproj;     // [192]
+};
+struct TailArgs {
+    const _Float16* X;      // [B][49][192]
+    _Float16* Y;            // [B][49][192]
+    int B, nblk;
+    const TailBlock* blk;   // device table, nblk consecutive rows
+    _Float16* dbg_dw;       // optional [B][49][1152]: depthwise output of the last block run (nblk == 1)
+    float* dbg_gate;        // optional [B][1152]
+};
+int launch_tail7(const TailArgs& a, hipStream_t st);
+
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 int launch_mbconv_d(const MbArgs& a, hipStream_t st);   // dot2 depthwise variant (pair-interleaved LDS tile)
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,

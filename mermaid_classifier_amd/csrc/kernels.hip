@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void se_gemm_f32_kernel(const float* __restric
 //   FC2  gate[16][C] = sigmoid(be + r . We^T): the 16 waves split the C/16 output fragments, r comes from LDS.
 // ---------------------------------------------------------------------------------------------
 #define SE_MAXG 5   // k-groups (16 k each) a wave may own in FC1: C <= 16 waves * 5 * 16 = 1280
-#define SE_MAXT 2   // output fragments a wave may own in FC2 (after the gridDim.y split)
+#define SE_MAXT 1   // output fragments a wave may own in FC2 (after the gridDim.y split)
 // Weights are fp32 (fp16 storage was tried: the gate error it causes is coherent per channel and
 // roughly doubled the end-to-end feature error), packed in MFMA fragment order (16 bytes per lane,
 // 1 KB per fragment, contiguous -> perfectly coalesced loads):
@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256) void se_gemm_f32_kernel(const float* __restric
 //   WeP[(T*3 + g)*64 + lane][4] = We[16T + i][16g + 4q .. +4]      (zero for k >= Cs)
 // gridDim = (ceil(M/16), NSPLIT): every y-slice recomputes FC1 (cheap) and owns 1/NSPLIT of FC2's outputs,
 // so the weight stream of one patch group is spread over NSPLIT compute units.
+template <int MAXG>
 __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict__ pool_part, int nslab, int M, int C,
                                                         int Cs4, const float* __restrict__ WrP,
                                                         const float* __restrict__ br,  // [48] zero padded
@@ -561,12 +562,31 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
     const int row = blockIdx.x * 16 + i;
     const bool rok = row < M;
     const int NG = C >> 4;            // k-groups of FC1 == output fragments of FC2
+    const int per_y = (NG + gridDim.y - 1) / gridDim.y;
+    const int t_lo = blockIdx.y * per_y;
+    const int t_hi = (t_lo + per_y) < NG ? (t_lo + per_y) : NG;
+    // FC2's weight fragments and bias do not depend on FC1: issue their loads first so the whole kernel
+    // is one memory round trip (pool partials, Wr, We, be all in flight together)
+    f4 we[SE_MAXT][3];
+    f4 bev[SE_MAXT];
+#pragma unroll
+    for (int u = 0; u < SE_MAXT; ++u) {
+        const int T = t_lo + wave + 16 * u;
+        bev[u] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (T < t_hi) bev[u] = *reinterpret_cast<const f4*>(be + T * 16 + 4 * q);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            f4 w = {0.f, 0.f, 0.f, 0.f};
+            if (T < t_hi) w = *reinterpret_cast<const f4*>(WeP + ((size_t)(T * 3 + g) * 64 + lane) * 4);
+            we[u][g] = w;
+        }
+    }
     // ---- FC1: this wave owns k-groups g = wave, wave+16, ... ----
     {
-        f4 xv[SE_MAXG];
-        f4 wv[SE_MAXG][3];
+        f4 xv[MAXG];
+        f4 wv[MAXG][3];
 #pragma unroll
-        for (int u = 0; u < SE_MAXG; ++u) {
+        for (int u = 0; u < MAXG; ++u) {
             const int g = wave + 16 * u;
             const bool gok = g < NG;
             const int k = g * 16 + 4 * q;
@@ -575,6 +595,20 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
                 const float* xp = pool_part + (size_t)row * nslab * C + k;
                 f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
                 int p = 0;
+                if (MAXG <= 2) {   // early blocks: many slabs, few channels -> 16 independent loads per round trip
+                    for (; p + 15 < nslab; p += 16) {
+                        f4 v[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = *reinterpret_cast<const f4*>(xp + (size_t)(p + e) * C);
+#pragma unroll
+                        for (int e = 0; e < 16; e += 4) {
+                            s0 += v[e];
+                            s1 += v[e + 1];
+                            s2 += v[e + 2];
+                            s3 += v[e + 3];
+                        }
+                    }
+                }
                 for (; p + 3 < nslab; p += 4) {
                     s0 += *reinterpret_cast<const f4*>(xp + (size_t)p * C);
                     s1 += *reinterpret_cast<const f4*>(xp + (size_t)(p + 1) * C);
@@ -596,7 +630,7 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < SE_MAXG; ++u)
+        for (int u = 0; u < MAXG; ++u)
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -617,23 +651,9 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
     __syncthreads();
     // ---- FC2: output fragments T = y*per_y + wave + 16u ----
     {
-        const int per_y = (NG + gridDim.y - 1) / gridDim.y;
-        const int t_lo = blockIdx.y * per_y;
-        const int t_hi = (t_lo + per_y) < NG ? (t_lo + per_y) : NG;
         f4 xr[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(&rs[i][g * 16 + 4 * q]);
-        f4 wv[SE_MAXT][3];
-#pragma unroll
-        for (int u = 0; u < SE_MAXT; ++u) {
-            const int T = t_lo + wave + 16 * u;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                f4 w = {0.f, 0.f, 0.f, 0.f};
-                if (T < t_hi) w = *reinterpret_cast<const f4*>(WeP + ((size_t)(T * 3 + g) * 64 + lane) * 4);
-                wv[u][g] = w;
-            }
-        }
 #pragma unroll
         for (int u = 0; u < SE_MAXT; ++u) {
             const int T = t_lo + wave + 16 * u;
@@ -643,10 +663,10 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], xr[g][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(we[u][g][s], xr[g][s], acc, 0, 0, 0);
             if (rok) {
                 const int n = T * 16 + 4 * q;
-                const f4 bv = *reinterpret_cast<const f4*>(be + n);
+                const f4 bv = bev[u];
                 f4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j] + bv[j]);
@@ -1297,6 +1317,313 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// tail7_kernel: the 7x7 MBConv blocks b12..b14 (192 -> 1152 -> 192, k5 s1, squeeze-excite, skip) of ONE
+// patch per workgroup, chained inside the CU's 160 KB of LDS: the block input/output X[49][192] and the
+// expanded tensor ED[49][1152] never leave the CU, squeeze-excite needs no second launch (the whole
+// patch is local), and a 3-block chain is one launch instead of nine.  512 threads = 8 waves.
+//   expand   swapped MFMA (A = weight fragments streamed from L2, B = pixel fragments held in registers for
+//            the whole phase); wave w owns expanded channels [144w, 144w+144); silu -> ED fp16.
+//   dw       thread = one expanded channel: its 49 inputs become 28 pixel-pair dwords in registers, the 49
+//            outputs run on v_dot2c (same tap pairs and order as mbconv_d_kernel), silu, written back IN PLACE
+//            (a channel's column is private to its thread), pooled sum -> LDS.
+//   SE       FC1 / FC2 on the exact-f32 MFMA with the fragment-packed weights of se_fused_kernel (the 16
+//            patch columns of the fragment are all this patch); 8 waves split K resp. the output fragments.
+//   gate     ED <- fp16(ED * gate) in place (same rounding as pw_gemm_kernel's gate-at-load).
+//   project  swapped MFMA (A = weight fragments from L2, 4 k-steps ahead; B = pixels from ED); waves 0..3 own
+//            two 16-channel output fragments, waves 4..7 one (12 fragments; every SIMD gets three);
+//            + bias + residual -> X in place.
+// Pixels enumerate y*7+x; a 16-pixel MFMA fragment past pixel 48 re-reads pixel 48 and is dropped.
+// ---------------------------------------------------------------------------------------------
+#define T7_PIX 49
+#define T7_C 192
+#define T7_CE 1152
+#define T7_XS 400                                    // X row stride, bytes
+#define T7_ES 2320                                   // ED row stride, bytes (580 dwords = 4 mod 64 banks)
+#define T7_OFF_X (T7_PIX * T7_ES)
+#define T7_OFF_POOL (T7_OFF_X + T7_PIX * T7_XS)
+#define T7_OFF_GATE (T7_OFF_POOL + T7_CE * 4)
+#define T7_OFF_PART (T7_OFF_GATE + T7_CE * 4)
+#define T7_OFF_RS (T7_OFF_PART + 8 * 48 * 4)
+#define T7_LDS (T7_OFF_RS + 48 * 4)
+
+__global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ED = smem;
+    unsigned char* XL = smem + T7_OFF_X;
+    float* pooled = reinterpret_cast<float*>(smem + T7_OFF_POOL);
+    float* gate = reinterpret_cast<float*>(smem + T7_OFF_GATE);
+    float* part = reinterpret_cast<float*>(smem + T7_OFF_PART);
+    float* rs = reinterpret_cast<float*>(smem + T7_OFF_RS);
+    const int tid0 = threadIdx.x;
+    const int b = blockIdx.x;
+    {
+        const int tid = tid0;
+        const _Float16* xg = a.X + (size_t)b * T7_PIX * T7_C;
+        for (int e = tid; e < T7_PIX * 24; e += 512) {
+            const int pix = e / 24, p16 = e - pix * 24;
+            *reinterpret_cast<h8*>(XL + pix * T7_XS + p16 * 16) = *reinterpret_cast<const h8*>(xg + pix * T7_C + p16 * 8);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int nb = 0; nb < a.nblk; ++nb) {
+        const TailBlock W = a.blk[nb];   // scalar loads of one table row
+        // Thread indices are re-derived through an opaque move every iteration: otherwise the compiler hoists the
+        // ~150 loop-invariant weight-fragment addresses of all phases out of the block loop and spills them.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int m = lane & 15, q = lane >> 4;
+        int pixc[4];   // this lane's pixel in each of the four pixel fragments (clamped)
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) pixc[pf] = (16 * pf + m) < T7_PIX ? (16 * pf + m) : (T7_PIX - 1);
+        // ---------------- expand: ED = silu(X . Wexp^T + b) ----------------
+        {
+            h8 xb[4][6];
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks)
+                    xb[pf][ks] = *reinterpret_cast<const h8*>(XL + pixc[pf] * T7_XS + (32 * ks + 8 * q) * 2);
+            const h8* wf = reinterpret_cast<const h8*>(W.wexp) + lane;
+            h8 wn[6];
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) wn[ks] = wf[(size_t)((9 * wave) * 6 + ks) * 64];
+#pragma unroll 1
+            for (int i = 0; i < 9; ++i) {
+                const int nf = 9 * wave + i;
+                h8 wc[6];
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
+                if (i + 1 < 9) {
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) wn[ks] = wf[(size_t)((nf + 1) * 6 + ks) * 64];
+                }
+                const f4 bv = *reinterpret_cast<const f4*>(W.bexp + 16 * nf + 4 * q);
+                f4 acc[4];
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+                        acc[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[pf][ks], acc[pf], 0, 0, 0);
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) {
+                    if (16 * pf + m < T7_PIX) {
+                        h4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[pf][j]);
+                        *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_ES + (16 * nf + 4 * q) * 2) = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- depthwise 5x5 + silu, in place; pooled sums ----------------
+#pragma unroll 1
+        for (int c = tid; c < T7_CE; c += 512) {
+            uint32_t wp[30];
+#pragma unroll
+            for (int i = 0; i < 30; ++i) wp[i] = W.dwp[i * T7_CE + c];
+            const float bias = W.bdw[c];
+            unsigned char* col = ED + 2 * c;
+            uint32_t P[28];
+#pragma unroll
+            for (int y = 0; y < 7; ++y)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp) * T7_ES);
+                    uint32_t hi = 0;
+                    if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp + 1) * T7_ES);
+                    P[y * 4 + pp] = lo | (hi << 16);
+                }
+            float psum = 0.f;
+#pragma unroll
+            for (int oy = 0; oy < 7; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 7; ++ox) {
+                    float acc = bias;
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const int iy = oy - 2 + ky;
+                        if (iy < 0 || iy >= 7) continue;
+#pragma unroll
+                        for (int ip = 0; ip < 3; ++ip) {
+                            const int xpc = (ox >> 1) - 1 + ip;
+                            if (xpc < 0 || xpc > 3) continue;
+                            acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
+                                                         *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * 3 + ip]), acc,
+                                                         false);
+                        }
+                    }
+                    const float y = silu_scaled(acc);
+                    psum += y;
+                    *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
+                }
+            pooled[c] = psum;
+        }
+        __syncthreads();
+        if (a.dbg_dw) {
+            _Float16* dg = a.dbg_dw + (size_t)b * T7_PIX * T7_CE;
+            for (int e = tid; e < T7_PIX * 144; e += 512) {
+                const int pix = e / 144, oc = e - pix * 144;
+                *reinterpret_cast<h8*>(dg + pix * T7_CE + oc * 8) = *reinterpret_cast<const h8*>(ED + pix * T7_ES + oc * 16);
+            }
+        }
+        // ---------------- squeeze-excite FC1: r = silu(br + pooled . Wr^T) ----------------
+        {
+            f4 xv[9], wv[9][3];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                const int g = 9 * wave + u;
+                xv[u] = *reinterpret_cast<const f4*>(pooled + 16 * g + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) wv[u][t] = *reinterpret_cast<const f4*>(W.wrp + ((size_t)(g * 3 + t) * 64 + lane) * 4);
+            }
+            f4 acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t][s], xv[u][s], acc[t], 0, 0, 0);
+            if (m == 0) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(part + wave * 48 + 16 * t + 4 * q) = acc[t];
+            }
+        }
+        __syncthreads();
+        if (tid < 48) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[w * 48 + tid];
+            rs[tid] = silu_f(s + W.br[tid]);
+        }
+        __syncthreads();
+        // ---------------- FC2: gate = sigmoid(be + r . We^T) ----------------
+        {
+            f4 xr[3], wv[9][3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(rs + 16 * g + 4 * q);
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    wv[u][g] = *reinterpret_cast<const f4*>(W.wep + ((size_t)((9 * wave + u) * 3 + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], xr[g][s], acc, 0, 0, 0);
+                if (m == 0) {
+                    const int n = (9 * wave + u) * 16 + 4 * q;
+                    const f4 bv = *reinterpret_cast<const f4*>(W.be + n);
+                    f4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j] + bv[j]);
+                    *reinterpret_cast<f4*>(gate + n) = o;
+                }
+            }
+        }
+        __syncthreads();
+        if (a.dbg_gate) {
+            for (int e = tid; e < T7_CE; e += 512) a.dbg_gate[(size_t)b * T7_CE + e] = gate[e];
+        }
+        // ---------------- gate, in place ----------------
+        for (int e = tid; e < T7_PIX * 144; e += 512) {
+            const int pix = e / 144, oc = e - pix * 144;
+            h8* pv = reinterpret_cast<h8*>(ED + pix * T7_ES + oc * 16);
+            h8 v = *pv;
+            const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
+            const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (_Float16)((float)v[j] * g0[j]);
+                v[4 + j] = (_Float16)((float)v[4 + j] * g1[j]);
+            }
+            *pv = v;
+        }
+        __syncthreads();
+        // ---------------- project + bias + residual -> X in place ----------------
+        {
+            const bool two = wave < 4;
+            const int nf0 = two ? 2 * wave : 4 + wave;
+            const int nf1 = two ? nf0 + 1 : nf0;
+            f4 acc0[4], acc1[4];
+            {
+                const f4 b0 = *reinterpret_cast<const f4*>(W.bproj + 16 * nf0 + 4 * q);
+                const f4 b1 = *reinterpret_cast<const f4*>(W.bproj + 16 * nf1 + 4 * q);
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) { acc0[pf] = b0; acc1[pf] = b1; }
+            }
+            const h8* wf0 = reinterpret_cast<const h8*>(W.wproj) + (size_t)nf0 * 36 * 64 + lane;
+            const h8* wf1 = reinterpret_cast<const h8*>(W.wproj) + (size_t)nf1 * 36 * 64 + lane;
+            h8 wa0[4], wa1[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                wa0[d] = wf0[d * 64];
+                if (two) wa1[d] = wf1[d * 64];
+            }
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < 36; ks0 += 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ks = ks0 + d;
+                    h8 bx[4];
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+                        bx[pf] = *reinterpret_cast<const h8*>(ED + pixc[pf] * T7_ES + (32 * ks + 8 * q) * 2);
+                    const h8 w0 = wa0[d], w1 = wa1[d];
+                    if (ks + 4 < 36) {
+                        wa0[d] = wf0[(ks + 4) * 64];
+                        if (two) wa1[d] = wf1[(ks + 4) * 64];
+                    }
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) acc0[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bx[pf], acc0[pf], 0, 0, 0);
+                    if (two) {
+#pragma unroll
+                        for (int pf = 0; pf < 4; ++pf)
+                            acc1[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bx[pf], acc1[pf], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+                if (16 * pf + m >= T7_PIX) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !two) continue;
+                    const int nf = i ? nf1 : nf0;
+                    h4* px = reinterpret_cast<h4*>(XL + (16 * pf + m) * T7_XS + (16 * nf + 4 * q) * 2);
+                    const h4 r = *px;
+                    h4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)((i ? acc1[pf][j] : acc0[pf][j]) + (float)r[j]);
+                    *px = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {
+        const int tid = tid0;
+        _Float16* yg = a.Y + (size_t)b * T7_PIX * T7_C;
+        for (int e = tid; e < T7_PIX * 24; e += 512) {
+            const int pix = e / 24, p16 = e - pix * 24;
+            *reinterpret_cast<h8*>(yg + pix * T7_C + p16 * 8) = *reinterpret_cast<const h8*>(XL + pix * T7_XS + p16 * 16);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused stem + block-0 depthwise: u8 patch -> [stem conv3x3s2 + bias + SiLU] -> LDS -> [depthwise 3x3 s1 +
 // bias + SiLU] -> fp16 NHWC (112x112x32) + squeeze-excite partial sums.  The 112x112x32 stem output (the
 // largest tensor of the net after the expanded ones) never goes to HBM.  Same two-phase structure as
@@ -1610,8 +1937,14 @@ int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, co
     const int ng = C / 16;
     int nsplit = (ng + 16 * SE_MAXT - 1) / (16 * SE_MAXT);   // each y-slice covers <= 16 waves * SE_MAXT fragments
     if (ng >= 30 && nsplit < 4) nsplit = 4;                  // big layers: spread the weight stream over 4 CUs
-    hipLaunchKernelGGL(se_fused_kernel, dim3((B + 15) / 16, nsplit), dim3(1024), 0, st, pool_part, nparts, B, C, Cs4, WrP,
-                       br, WeP, be, gate);
+    const dim3 grid((B + 15) / 16, nsplit);
+    const int maxg = (ng + 15) / 16;                         // FC1 k-groups per wave
+#define SE_LAUNCH(G) hipLaunchKernelGGL((se_fused_kernel<G>), grid, dim3(1024), 0, st, pool_part, nparts, B, C, Cs4, WrP, br, WeP, be, gate)
+    if (maxg <= 1) SE_LAUNCH(1);
+    else if (maxg <= 2) SE_LAUNCH(2);
+    else if (maxg <= 3) SE_LAUNCH(3);
+    else SE_LAUNCH(SE_MAXG);
+#undef SE_LAUNCH
     LAUNCH_CHECK();
     return 0;
 }
@@ -1740,4 +2073,19 @@ int launch_mbconv_d(const MbArgs& a, hipStream_t st)
     MD_CASE(5, 1, 6, 1, 96, 7, 2)     // b12-b14
 #undef MD_CASE
     return -5;
+}
+
+int launch_tail7(const TailArgs& a, hipStream_t st)
+{
+    if (a.nblk < 1 || a.nblk > 3 || a.B < 1) return -9;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, T7_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(tail7_kernel, dim3(a.B), dim3(512), T7_LDS, st, a);
+    LAUNCH_CHECK();
+    return 0;
 }

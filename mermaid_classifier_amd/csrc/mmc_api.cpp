@@ -115,6 +115,9 @@ struct BlockW {
     bool use_d = false;
     int d_npair = 0, d_wl_off = 0, d_red_off = 0, d_lds = 0;
     _Float16* exp_frag = nullptr;  // expand weights in MFMA fragment order
+    // tail7_kernel packing (7x7 blocks 12..14): project weights in plain fragment order, depthwise tap pairs
+    _Float16* t_wproj = nullptr;
+    uint32_t* t_dwp = nullptr;
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
@@ -157,6 +160,7 @@ struct mmc_backbone {
     size_t ws_bytes = 0;
     std::vector<void*> allocs;
     bool keep = false, fuse_stem = false;
+    TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     std::map<std::string, Saved> saved;
     int last_n = 0;
 };
@@ -325,6 +329,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
     bb->fuse_stem = fuse_enabled;
+    const char* tail_env = getenv("MMC_TAIL");
+    const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
     int H = IMG / 2;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
     int max_c = 0;
@@ -358,6 +364,24 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
+            if (tail_enabled && i >= 12 && i <= 14) {
+                // tap pairs of tail7_kernel, same values as mbconv_d_kernel's wl2: pair (ky, t, ip) holds taps
+                // kx0 = 2*ip - t and kx0 + 1 of kernel row ky (zero outside [0, 5)) as fp16
+                std::vector<uint32_t> dp((size_t)30 * B.ce, 0u);
+                for (int c = 0; c < B.ce; ++c)
+                    for (int ky = 0; ky < 5; ++ky)
+                        for (int t = 0; t < 2; ++t)
+                            for (int ip = 0; ip < 3; ++ip) {
+                                const int kx0 = 2 * ip - t;
+                                _Float16 h[2] = {(_Float16)0.0f, (_Float16)0.0f};
+                                if (kx0 >= 0 && kx0 < 5) h[0] = (_Float16)w[(size_t)c * kk + ky * 5 + kx0];
+                                if (kx0 + 1 >= 0 && kx0 + 1 < 5) h[1] = (_Float16)w[(size_t)c * kk + ky * 5 + kx0 + 1];
+                                uint32_t u;
+                                memcpy(&u, h, 4);
+                                dp[(size_t)((ky * 2 + t) * 3 + ip) * B.ce + c] = u;
+                            }
+                TRY_OR_FREE(dev_upload(bb, &B.t_dwp, dp));
+            }
         }
         {
             snprintf(nm, sizeof nm, "b%d.se", i);
@@ -395,6 +419,16 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
             TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
+            if (tail_enabled && i >= 12 && i <= 14) {
+                // plain MFMA fragment order [cout/16][ce/32][64 lanes][8]: lane (q*16 + m) holds W[16nf + m][32ks + 8q ..+8]
+                const int ks32 = B.ce / 32;
+                std::vector<_Float16> wf((size_t)B.d.cout * B.ce);
+                for (int c = 0; c < B.d.cout; ++c)
+                    for (int k = 0; k < B.ce; ++k)
+                        wf[((((size_t)(c / 16) * ks32 + k / 32) * 64) + ((k % 32) / 8) * 16 + (c % 16)) * 8 + (k % 8)] =
+                            (_Float16)(float)(w[(size_t)c * B.ce + k] * (1.0 / LOG2E));
+                TRY_OR_FREE(dev_upload(bb, &B.t_wproj, wf));
+            }
         }
         // depthwise geometry
         B.tw = (B.Ho % 4 == 0) ? 4 : (B.Ho % 7 == 0 && B.Ho <= 7 ? 7 : 2);
@@ -485,6 +519,14 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
         TAKE(b, FEAT, "head.bias");
         TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
+    }
+    if (tail_enabled && bb->blk[12].exp_frag && bb->blk[13].exp_frag && bb->blk[14].exp_frag) {
+        std::vector<TailBlock> tab(3);
+        for (int j = 0; j < 3; ++j) {
+            const BlockW& B = bb->blk[12 + j];
+            tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.se_wrp, B.se_br, B.se_wep, B.se_be, B.t_wproj, B.project.b};
+        }
+        TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -605,6 +647,30 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     }
     for (int i = 0; i < 16; ++i) {
+        if (i == 12 && bb->tail_tab) {
+            // blocks 12..14 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
+            if (!bb->keep) {
+                TailArgs ta{x, y, n, 3, bb->tail_tab, nullptr, nullptr};
+                STEP("b12-14.tail", "tail7", launch_tail7(ta, st));
+                _Float16* t = x; x = y; y = t;
+            } else {
+                for (int j = 0; j < 3; ++j) {   // block at a time so every intermediate tensor can be read back
+                    TailArgs ta{x, y, n, 1, bb->tail_tab + j, ws.dwbuf, ws.gate};
+                    snprintf(nm, sizeof nm, "b%d.tail", 12 + j);
+                    STEP(nm, "tail7", launch_tail7(ta, st));
+                    int r;
+                    snprintf(nm, sizeof nm, "b%d.dw", 12 + j);
+                    if ((r = save_act(bb, nm, ws.dwbuf, (size_t)n * 49 * bb->blk[12 + j].ce, true, st))) return r;
+                    snprintf(nm, sizeof nm, "b%d.gate", 12 + j);
+                    if ((r = save_act(bb, nm, ws.gate, (size_t)n * bb->blk[12 + j].ce, false, st))) return r;
+                    snprintf(nm, sizeof nm, "b%d.out", 12 + j);
+                    if ((r = save_act(bb, nm, y, (size_t)n * 49 * 192, true, st))) return r;
+                    _Float16* t = x; x = y; y = t;
+                }
+            }
+            i = 14;
+            continue;
+        }
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;

@@ -44,6 +44,10 @@ def b0_launches(batch: int) -> List[Launch]:
         out.append(Launch(f"b{i}.project", "project", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2,
                           2 * m_out * ce * cout))
         h = ho
+    # blocks 12..14 chained in one launch (tail7_kernel): only the 7x7x192 block input/output and the weights move
+    tail = [l for l in out if l.name.split(".")[0] in ("b12", "b13", "b14") and l.kind in ("mbconv", "se", "project")]
+    w_bytes = sum(1152 * 192 * 2 * 2 + 30 * 1152 * 4 + 2 * 48 * 1152 * 4 for _ in range(3))
+    out.append(Launch("b12-14.tail", "tail", 2 * batch * 49 * 192 * 2 + w_bytes, sum(l.flops for l in tail)))
     out.append(Launch("head", "head", batch * h * h * 320 * 2 + batch * FEATURE_DIM * 4 + FEATURE_DIM * 320 * 2,
                       2 * batch * h * h * 320 * FEATURE_DIM))
     return out
@@ -56,7 +60,7 @@ def totals(batch: int, launched=None) -> Dict[str, float]:
         names = set(launched)
         ls = [l for l in ls if l.name in names]
     else:
-        ls = [l for l in ls if l.kind not in ("mbconv", "stem_dw")]
+        ls = [l for l in ls if l.kind not in ("mbconv", "stem_dw", "tail")]
     return {"bytes": float(sum(l.bytes for l in ls)), "flops": float(sum(l.flops for l in ls)),
             "bytes_per_patch": sum(l.bytes for l in ls) / batch, "flops_per_patch": sum(l.flops for l in ls) / batch}
 
