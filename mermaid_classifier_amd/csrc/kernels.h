@@ -52,9 +52,12 @@ struct MbArgs {
 struct TailBlock {
     const _Float16* wexp;   // [72][6][64][8] expand weights, MFMA fragment order
     const float* bexp;      // [1152]
-    const uint32_t* dwp;    // [30][1152] depthwise tap pairs (fp16 x2): index (ky*2 + t)*3 + ip
+    const uint32_t* dwp;    // [15][1152] depthwise taps as fp16 pairs: row ky = (k0,k1), (k2,k3), (k4,0)
     const float* bdw;       // [1152]
-    const float *wrp, *br, *wep, *be;   // squeeze-excite, as se_fused_kernel
+    const _Float16* wr_t;   // [1152][48] squeeze FC, channel-major (unscaled: 1/(49*log2e) is applied in fp32)
+    const float* br;        // [48]
+    const _Float16* we_t;   // [48][1152] excite FC, k-major
+    const float* be;        // [1152]
     const _Float16* wproj;  // [12][36][64][8] project weights, MFMA fragment order
     const float* bproj;     // [192]
 };
@@ -65,6 +68,7 @@ struct TailArgs {
     const TailBlock* blk;   // device table, nblk consecutive rows
     _Float16* dbg_dw;       // optional [B][49][1152]: depthwise output of the last block run (nblk == 1)
     float* dbg_gate;        // optional [B][1152]
+    float* dbg_clk;         // optional [B][8]: shader cycles per phase (expand, dw, fc1, fc2, gate, project)
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 

@@ -15,6 +15,7 @@
 //   crop_kernel        pyspacer crop_patches (reflect pad + slice)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -1326,8 +1327,9 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 //   dw       thread = one expanded channel: its 49 inputs become 28 pixel-pair dwords in registers, the 49
 //            outputs run on v_dot2c (same tap pairs and order as mbconv_d_kernel), silu, written back IN PLACE
 //            (a channel's column is private to its thread), pooled sum -> LDS.
-//   SE       FC1 / FC2 on the exact-f32 MFMA with the fragment-packed weights of se_fused_kernel (the 16
-//            patch columns of the fragment are all this patch); 8 waves split K resp. the output fragments.
+//   SE       both FCs are matrix-vector products here: fp32 FMAs on fp16 weights (measured effect on the features
+//            3e-5 relative), coalesced loads, fixed order.
+// Weight streams are requested one phase ahead (registers) so that the L2 round trips hide behind compute.
 //   gate     ED <- fp16(ED * gate) in place (same rounding as pw_gemm_kernel's gate-at-load).
 //   project  swapped MFMA (A = weight fragments from L2, 4 k-steps ahead; B = pixels from ED); waves 0..3 own
 //            two 16-channel output fragments, waves 4..7 one (12 fragments; every SIMD gets three);
@@ -1343,8 +1345,30 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 #define T7_OFF_POOL (T7_OFF_X + T7_PIX * T7_XS)
 #define T7_OFF_GATE (T7_OFF_POOL + T7_CE * 4)
 #define T7_OFF_PART (T7_OFF_GATE + T7_CE * 4)
-#define T7_OFF_RS (T7_OFF_PART + 8 * 48 * 4)
+#define T7_OFF_RS (T7_OFF_PART + 32 * 48 * 4)
 #define T7_LDS (T7_OFF_RS + 48 * 4)
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+// a pointer that came out of memory, moved to SGPRs (wave-uniform by construction) and to the global address space
+template <typename T>
+static __device__ __forceinline__ const GLOBAL_AS T* sgpr_ptr(const void* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const GLOBAL_AS T*>(((uint64_t)hi << 32) | lo);
+}
+// global load from a wave-uniform base plus a 32-bit byte offset: global_load ... v_off, s[base:base+1] (no 64-bit
+// address arithmetic in VGPRs)
+template <typename T>
+static __device__ __forceinline__ T gload(const GLOBAL_AS void* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const GLOBAL_AS T*>(reinterpret_cast<const GLOBAL_AS char*>(base) + byte_off);
+}
+// Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), NOT for its outstanding global loads:
+// __syncthreads() also drains vmcnt, which would serialise every weight prefetch issued across a phase boundary.
+// No global data is exchanged between the threads of this kernel, so the LDS-only form is sufficient.
+#define T7_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 {
@@ -1368,16 +1392,50 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
     __syncthreads();
 #pragma unroll 1
     for (int nb = 0; nb < a.nblk; ++nb) {
-        const TailBlock W = a.blk[nb];   // scalar loads of one table row
+        // One table row via scalar loads.  Pointers that come out of memory are "flat" to the compiler; the casts
+        // restore the global address space so the weight streams are global_load (vmcnt only), not flat_load.
+        const TailBlock Wt = a.blk[nb];
+        struct {
+            const GLOBAL_AS _Float16* wexp; const GLOBAL_AS float* bexp; const GLOBAL_AS uint32_t* dwp; const GLOBAL_AS float* bdw;
+            const GLOBAL_AS _Float16* wr_t; const GLOBAL_AS float* br; const GLOBAL_AS _Float16* we_t; const GLOBAL_AS float* be;
+            const GLOBAL_AS _Float16* wproj; const GLOBAL_AS float* bproj;
+        } W = {sgpr_ptr<_Float16>(Wt.wexp), sgpr_ptr<float>(Wt.bexp), sgpr_ptr<uint32_t>(Wt.dwp), sgpr_ptr<float>(Wt.bdw),
+               sgpr_ptr<_Float16>(Wt.wr_t), sgpr_ptr<float>(Wt.br), sgpr_ptr<_Float16>(Wt.we_t), sgpr_ptr<float>(Wt.be),
+               sgpr_ptr<_Float16>(Wt.wproj), sgpr_ptr<float>(Wt.bproj)};
         // Thread indices are re-derived through an opaque move every iteration: otherwise the compiler hoists the
         // ~150 loop-invariant weight-fragment addresses of all phases out of the block loop and spills them.
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int m = lane & 15, q = lane >> 4;
+        long long tk[7];
+        int ntk = 0;
+#define T7_TICK() do { if (a.dbg_clk) tk[ntk] = (long long)__builtin_readcyclecounter(); ++ntk; } while (0)
+        T7_TICK();
         int pixc[4];   // this lane's pixel in each of the four pixel fragments (clamped)
 #pragma unroll
         for (int pf = 0; pf < 4; ++pf) pixc[pf] = (16 * pf + m) < T7_PIX ? (16 * pf + m) : (T7_PIX - 1);
+        // Depthwise taps of this thread's first channel: issued now, they arrive while the expand phase computes.
+        // (15 dwords per channel: kernel row ky = (k0,k1), (k2,k3), (k4,0) as fp16 pairs.)
+        uint32_t rawA[15], rawB[15];
+        float biasA, biasB;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + tid) * 4u);
+        biasA = gload<float>(W.bdw, (unsigned)tid * 4u);
+        // the six tap pairs of a kernel row: output x even uses (k0,k1)(k2,k3)(k4,0) on pixel pairs starting at x-2,
+        // output x odd uses (0,k0)(k1,k2)(k3,k4) on pairs starting at x-3 -- the same values mbconv_d_kernel keeps in LDS
+        auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[30]) {
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                wp[(ky * 2 + 0) * 3 + 0] = r0;
+                wp[(ky * 2 + 0) * 3 + 1] = r1;
+                wp[(ky * 2 + 0) * 3 + 2] = r2;
+                wp[(ky * 2 + 1) * 3 + 0] = r0 << 16;
+                wp[(ky * 2 + 1) * 3 + 1] = __builtin_amdgcn_alignbit(r1, r0, 16);
+                wp[(ky * 2 + 1) * 3 + 2] = __builtin_amdgcn_alignbit(r2, r1, 16);
+            }
+        };
         // ---------------- expand: ED = silu(X . Wexp^T + b) ----------------
         {
             h8 xb[4][6];
@@ -1386,21 +1444,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks)
                     xb[pf][ks] = *reinterpret_cast<const h8*>(XL + pixc[pf] * T7_XS + (32 * ks + 8 * q) * 2);
-            const h8* wf = reinterpret_cast<const h8*>(W.wexp) + lane;
+            // Every workgroup streams the same weights at about the same time; rotating the fragment order by
+            // workgroup spreads the requests of the CUs that share an L2 over its channels.
+            const int rot = (b >> 3) % 9;
             h8 wn[6];
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) wn[ks] = wf[(size_t)((9 * wave) * 6 + ks) * 64];
+            for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)((((9 * wave + rot) * 6 + ks) * 64 + lane) * 16));
 #pragma unroll 1
             for (int i = 0; i < 9; ++i) {
-                const int nf = 9 * wave + i;
+                const int ir = i + rot >= 9 ? i + rot - 9 : i + rot;
+                const int nf = 9 * wave + ir;
                 h8 wc[6];
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
                 if (i + 1 < 9) {
+                    const int nfn = 9 * wave + (ir + 1 >= 9 ? ir + 1 - 9 : ir + 1);
 #pragma unroll
-                    for (int ks = 0; ks < 6; ++ks) wn[ks] = wf[(size_t)((nf + 1) * 6 + ks) * 64];
+                    for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)(((nfn * 6 + ks) * 64 + lane) * 16));
                 }
-                const f4 bv = *reinterpret_cast<const f4*>(W.bexp + 16 * nf + 4 * q);
+                const f4 bv = gload<f4>(W.bexp, (unsigned)(16 * nf + 4 * q) * 4u);
                 f4 acc[4];
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
@@ -1420,14 +1482,13 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
             }
         }
-        __syncthreads();
+        T7_BAR();
+        T7_TICK();
         // ---------------- depthwise 5x5 + silu, in place; pooled sums ----------------
-#pragma unroll 1
-        for (int c = tid; c < T7_CE; c += 512) {
+        // one full round: thread = one expanded channel c, all 49 pixels
+        auto dw_round = [&](int c, const uint32_t (&raw)[15], float bias) {
             uint32_t wp[30];
-#pragma unroll
-            for (int i = 0; i < 30; ++i) wp[i] = W.dwp[i * T7_CE + c];
-            const float bias = W.bdw[c];
+            tap_pairs(raw, wp);
             unsigned char* col = ED + 2 * c;
             uint32_t P[28];
 #pragma unroll
@@ -1441,30 +1502,113 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
             float psum = 0.f;
 #pragma unroll
-            for (int oy = 0; oy < 7; ++oy)
+            for (int oy = 0; oy < 7; ++oy) {
+                // the seven outputs of a row advance together (ox innermost): consecutive v_dot2c go to different
+                // accumulators, so no dependent-issue stalls
+                float acc[7];
 #pragma unroll
-                for (int ox = 0; ox < 7; ++ox) {
-                    float acc = bias;
+                for (int ox = 0; ox < 7; ++ox) acc[ox] = bias;
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky) {
-                        const int iy = oy - 2 + ky;
-                        if (iy < 0 || iy >= 7) continue;
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int iy = oy - 2 + ky;
+                    if (iy < 0 || iy >= 7) continue;
 #pragma unroll
-                        for (int ip = 0; ip < 3; ++ip) {
+                    for (int ip = 0; ip < 3; ++ip)
+#pragma unroll
+                        for (int ox = 0; ox < 7; ++ox) {
                             const int xpc = (ox >> 1) - 1 + ip;
                             if (xpc < 0 || xpc > 3) continue;
-                            acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
-                                                         *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * 3 + ip]), acc,
-                                                         false);
+                            acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
+                                                             *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * 3 + ip]),
+                                                             acc[ox], false);
                         }
-                    }
-                    const float y = silu_scaled(acc);
+                }
+#pragma unroll
+                for (int ox = 0; ox < 7; ++ox) {
+                    const float y = silu_scaled(acc[ox]);
                     psum += y;
                     *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
                 }
+            }
             pooled[c] = psum;
+        };
+        // taps of the next round are requested before the current round computes
+#pragma unroll
+        for (int i = 0; i < 15; ++i) rawB[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 512 + tid) * 4u);
+        biasB = gload<float>(W.bdw, (unsigned)(512 + tid) * 4u);
+        dw_round(tid, rawA, biasA);
+        const int cl = tid & 127, p4 = tid >> 7, rb = 2 * p4;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 1024 + cl) * 4u);
+        biasA = gload<float>(W.bdw, (unsigned)(1024 + cl) * 4u);
+        dw_round(512 + tid, rawB, biasB);
+        // Squeeze FC weights (fp16, 36 x 8 bytes per thread): requested before the last quarter round, which is pure
+        // VALU/LDS work (earlier the two tap buffers leave no registers for them).
+        const bool fc1_thr = tid < 384;
+        const int cr = tid / 12, j4 = tid - cr * 12;   // FC1: thread = 4 outputs j x channels cr, cr+32, ...
+        u2v fw1[36];   // 4 fp16 weights each, consumed by v_fma_mix_f32 without conversion
+        {
+            const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)
+#pragma unroll
+            for (int i = 0; i < 36; ++i) fw1[i] = gload<u2v>(W.wr_t, (unsigned)(((32 * i + crl) * 48 + 4 * j4) * 2));
         }
-        __syncthreads();
+        {
+            // Channels 1024..1151 (a quarter round) are shared by FOUR threads each so that all 8 waves stay busy:
+            // thread (channel, p) computes output rows 2p and 2p+1 from input rows 2p-2 .. 2p+3 (zeros outside the
+            // image).  In place needs every read of a channel before any write: barrier in between.
+            const int c = 1024 + cl;
+            uint32_t wpA[30];
+            tap_pairs(rawA, wpA);
+            unsigned char* col = ED + 2 * c;
+            uint32_t P[24];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = rb - 2 + r;
+                const bool rok = iy >= 0 && iy < 7;
+                const unsigned char* rowp = col + (rok ? iy : 0) * (7 * T7_ES);
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * T7_ES);
+                    uint32_t hi = 0;
+                    if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * T7_ES);
+                    P[r * 4 + pp] = rok ? (lo | (hi << 16)) : 0u;
+                }
+            }
+            T7_BAR();
+            float psum = 0.f;
+#pragma unroll
+            for (int ro = 0; ro < 2; ++ro) {
+                const int oy = rb + ro;
+                if (oy < 7) {
+                    float acc[7];
+#pragma unroll
+                    for (int ox = 0; ox < 7; ++ox) acc[ox] = biasA;
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                        for (int ip = 0; ip < 3; ++ip)
+#pragma unroll
+                            for (int ox = 0; ox < 7; ++ox) {
+                                const int xpc = (ox >> 1) - 1 + ip;
+                                if (xpc < 0 || xpc > 3) continue;
+                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[(ro + ky) * 4 + xpc]),
+                                                                 *reinterpret_cast<const h2*>(&wpA[(ky * 2 + (ox & 1)) * 3 + ip]),
+                                                                 acc[ox], false);
+                            }
+#pragma unroll
+                    for (int ox = 0; ox < 7; ++ox) {
+                        const float y = silu_scaled(acc[ox]);
+                        psum += y;
+                        *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
+                    }
+                }
+            }
+            part[p4 * 128 + cl] = psum;
+            T7_BAR();
+            if (tid < 128) pooled[1024 + tid] = ((part[tid] + part[128 + tid]) + part[256 + tid]) + part[384 + tid];
+        }
+        T7_BAR();
+        T7_TICK();
         if (a.dbg_dw) {
             _Float16* dg = a.dbg_dw + (size_t)b * T7_PIX * T7_CE;
             for (int e = tid; e < T7_PIX * 144; e += 512) {
@@ -1473,67 +1617,69 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
         }
         // ---------------- squeeze-excite FC1: r = silu(br + pooled . Wr^T) ----------------
-        {
-            f4 xv[9], wv[9][3];
+        // One patch per workgroup makes the two FCs matrix-VECTOR products: fp32 FMAs on fp16 weights (fixed
+        // summation order).  The excite weights (48 x 8 bytes per thread) are requested before FC1 computes.
+        const bool fc2_thr = tid < 288;   // FC2: thread = 4 consecutive channels
+        const float brv = tid < 48 ? gload<float>(W.br, (unsigned)tid * 4u) : 0.f;
+        if (fc1_thr) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int g = 9 * wave + u;
-                xv[u] = *reinterpret_cast<const f4*>(pooled + 16 * g + 4 * q);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) wv[u][t] = *reinterpret_cast<const f4*>(W.wrp + ((size_t)(g * 3 + t) * 64 + lane) * 4);
+            for (int i = 0; i < 36; ++i) {
+                const float x = pooled[32 * i + cr];
+                acc[0] = fma_mix_lo(fw1[i].x, x, acc[0]);
+                acc[1] = fma_mix_hi(fw1[i].x, x, acc[1]);
+                acc[2] = fma_mix_lo(fw1[i].y, x, acc[2]);
+                acc[3] = fma_mix_hi(fw1[i].y, x, acc[3]);
             }
-            f4 acc[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 9; ++u)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][t][s], xv[u][s], acc[t], 0, 0, 0);
-            if (m == 0) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) *reinterpret_cast<f4*>(part + wave * 48 + 16 * t + 4 * q) = acc[t];
-            }
+            *reinterpret_cast<f4*>(part + cr * 48 + 4 * j4) = acc;
         }
-        __syncthreads();
+        u2v fw2[48];
+        const int t2 = fc2_thr ? tid : 0;
+#pragma unroll
+        for (int k = 0; k < 48; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
+        const f4 bev = gload<f4>(W.be, (unsigned)t2 * 16u);
+        T7_BAR();
         if (tid < 48) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) s += part[w * 48 + tid];
-            rs[tid] = silu_f(s + W.br[tid]);
+            for (int w = 0; w < 32; ++w) s += part[w * 48 + tid];
+            // the pooled sums are over 49 pixels of log2(e)-scaled activations (kept out of the fp16 weights)
+            rs[tid] = silu_f(s * (float)(1.0 / (49.0 * 1.4426950408889634)) + brv);
         }
-        __syncthreads();
+        T7_BAR();
+        T7_TICK();
         // ---------------- FC2: gate = sigmoid(be + r . We^T) ----------------
-        {
-            f4 xr[3], wv[9][3];
+        if (fc2_thr) {
+            f4 acc = bev;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) xr[g] = *reinterpret_cast<const f4*>(rs + 16 * g + 4 * q);
-#pragma unroll
-            for (int u = 0; u < 9; ++u)
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    wv[u][g] = *reinterpret_cast<const f4*>(W.wep + ((size_t)((9 * wave + u) * 3 + g) * 64 + lane) * 4);
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][g][s], xr[g][s], acc, 0, 0, 0);
-                if (m == 0) {
-                    const int n = (9 * wave + u) * 16 + 4 * q;
-                    const f4 bv = *reinterpret_cast<const f4*>(W.be + n);
-                    f4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j] + bv[j]);
-                    *reinterpret_cast<f4*>(gate + n) = o;
-                }
+            for (int k = 0; k < 48; ++k) {
+                const float r = rs[k];
+                acc[0] = fma_mix_lo(fw2[k].x, r, acc[0]);
+                acc[1] = fma_mix_hi(fw2[k].x, r, acc[1]);
+                acc[2] = fma_mix_lo(fw2[k].y, r, acc[2]);
+                acc[3] = fma_mix_hi(fw2[k].y, r, acc[3]);
             }
+            f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j]);
+            *reinterpret_cast<f4*>(gate + 4 * tid) = o;
         }
-        __syncthreads();
+        // project: bias and the first four k-steps of weight fragments are requested before the gate pass
+        const bool two = wave < 4;
+        const int nf0 = two ? 2 * wave : 4 + wave;
+        const int nf1 = two ? nf0 + 1 : nf0;
+        const f4 pb0 = gload<f4>(W.bproj, (unsigned)(16 * nf0 + 4 * q) * 4u);
+        const f4 pb1 = gload<f4>(W.bproj, (unsigned)(16 * nf1 + 4 * q) * 4u);
+        const unsigned wo0 = (unsigned)((nf0 * 36 * 64 + lane) * 16);
+        const unsigned wo1 = (unsigned)((nf1 * 36 * 64 + lane) * 16);
+        h8 wa0[4], wa1[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            wa0[d] = gload<h8>(W.wproj, wo0 + (unsigned)(d * 1024));
+            wa1[d] = gload<h8>(W.wproj, wo1 + (unsigned)(d * 1024));
+        }
+        T7_BAR();
+        T7_TICK();
         if (a.dbg_gate) {
             for (int e = tid; e < T7_CE; e += 512) a.dbg_gate[(size_t)b * T7_CE + e] = gate[e];
         }
@@ -1551,50 +1697,51 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
             *pv = v;
         }
-        __syncthreads();
+        T7_BAR();
+        T7_TICK();
         // ---------------- project + bias + residual -> X in place ----------------
         {
-            const bool two = wave < 4;
-            const int nf0 = two ? 2 * wave : 4 + wave;
-            const int nf1 = two ? nf0 + 1 : nf0;
             f4 acc0[4], acc1[4];
-            {
-                const f4 b0 = *reinterpret_cast<const f4*>(W.bproj + 16 * nf0 + 4 * q);
-                const f4 b1 = *reinterpret_cast<const f4*>(W.bproj + 16 * nf1 + 4 * q);
 #pragma unroll
-                for (int pf = 0; pf < 4; ++pf) { acc0[pf] = b0; acc1[pf] = b1; }
-            }
-            const h8* wf0 = reinterpret_cast<const h8*>(W.wproj) + (size_t)nf0 * 36 * 64 + lane;
-            const h8* wf1 = reinterpret_cast<const h8*>(W.wproj) + (size_t)nf1 * 36 * 64 + lane;
-            h8 wa0[4], wa1[4];
+            for (int pf = 0; pf < 4; ++pf) { acc0[pf] = pb0; acc1[pf] = pb1; }
+            const unsigned char* bxp[4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                wa0[d] = wf0[d * 64];
-                if (two) wa1[d] = wf1[d * 64];
-            }
+            for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * T7_ES + 16 * q;
+            // NF = output fragments of this wave (2 for waves 0..3, 1 for waves 4..7): two straight-line loops instead of
+            // wave-uniform branches inside one.  Pixel fragments are read one k-step ahead of the MFMAs that use them,
+            // weight fragments four k-steps ahead.  The K order is part of the result: same for every workgroup.
+            auto k_loop = [&](auto nf_tag) {
+                constexpr int NF = decltype(nf_tag)::value;
+                h8 bx[4], bn[4];
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf]);
 #pragma unroll 1
-            for (int ks0 = 0; ks0 < 36; ks0 += 4) {
+                for (int ks0 = 0; ks0 < 36; ks0 += 4) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int ks = ks0 + d;
-                    h8 bx[4];
+                    for (int d = 0; d < 4; ++d) {
+                        const int ks = ks0 + d;
+                        const int kn = ks + 1 < 36 ? ks + 1 : 35;   // last step re-reads itself (unused)
 #pragma unroll
-                    for (int pf = 0; pf < 4; ++pf)
-                        bx[pf] = *reinterpret_cast<const h8*>(ED + pixc[pf] * T7_ES + (32 * ks + 8 * q) * 2);
-                    const h8 w0 = wa0[d], w1 = wa1[d];
-                    if (ks + 4 < 36) {
-                        wa0[d] = wf0[(ks + 4) * 64];
-                        if (two) wa1[d] = wf1[(ks + 4) * 64];
-                    }
-#pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) acc0[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bx[pf], acc0[pf], 0, 0, 0);
-                    if (two) {
+                        for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+                        const h8 w0 = wa0[d], w1 = wa1[d];
+                        const int kw = ks + 4 < 36 ? ks + 4 : 35;   // the last four prefetches re-read step 35 (unused)
+                        wa0[d] = gload<h8>(W.wproj, wo0 + (unsigned)(kw * 1024));
+                        if (NF == 2) wa1[d] = gload<h8>(W.wproj, wo1 + (unsigned)(kw * 1024));
 #pragma unroll
                         for (int pf = 0; pf < 4; ++pf)
-                            acc1[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bx[pf], acc1[pf], 0, 0, 0);
+                            acc0[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bx[pf], acc0[pf], 0, 0, 0);
+                        if (NF == 2) {
+#pragma unroll
+                            for (int pf = 0; pf < 4; ++pf)
+                                acc1[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bx[pf], acc1[pf], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
                     }
                 }
-            }
+            };
+            if (two) k_loop(std::integral_constant<int, 2>{});
+            else k_loop(std::integral_constant<int, 1>{});
 #pragma unroll
             for (int pf = 0; pf < 4; ++pf) {
                 if (16 * pf + m >= T7_PIX) continue;
@@ -1611,7 +1758,12 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
             }
         }
-        __syncthreads();
+        T7_BAR();
+        T7_TICK();
+#undef T7_TICK
+        if (a.dbg_clk && tid0 == 0) {   // cycles per phase of this block: expand, dw, fc1, fc2, gate, project
+            for (int i = 0; i < 6; ++i) a.dbg_clk[(size_t)b * 8 + i] = (float)(tk[i + 1] - tk[i]);
+        }
     }
     {
         const int tid = tid0;

@@ -118,6 +118,7 @@ struct BlockW {
     // tail7_kernel packing (7x7 blocks 12..14): project weights in plain fragment order, depthwise tap pairs
     _Float16* t_wproj = nullptr;
     uint32_t* t_dwp = nullptr;
+    _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
@@ -365,21 +366,18 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
             if (tail_enabled && i >= 12 && i <= 14) {
-                // tap pairs of tail7_kernel, same values as mbconv_d_kernel's wl2: pair (ky, t, ip) holds taps
-                // kx0 = 2*ip - t and kx0 + 1 of kernel row ky (zero outside [0, 5)) as fp16
-                std::vector<uint32_t> dp((size_t)30 * B.ce, 0u);
+                // taps of tail7_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
+                // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
+                std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
                 for (int c = 0; c < B.ce; ++c)
                     for (int ky = 0; ky < 5; ++ky)
-                        for (int t = 0; t < 2; ++t)
-                            for (int ip = 0; ip < 3; ++ip) {
-                                const int kx0 = 2 * ip - t;
-                                _Float16 h[2] = {(_Float16)0.0f, (_Float16)0.0f};
-                                if (kx0 >= 0 && kx0 < 5) h[0] = (_Float16)w[(size_t)c * kk + ky * 5 + kx0];
-                                if (kx0 + 1 >= 0 && kx0 + 1 < 5) h[1] = (_Float16)w[(size_t)c * kk + ky * 5 + kx0 + 1];
-                                uint32_t u;
-                                memcpy(&u, h, 4);
-                                dp[(size_t)((ky * 2 + t) * 3 + ip) * B.ce + c] = u;
-                            }
+                        for (int d = 0; d < 3; ++d) {
+                            _Float16 h[2] = {(_Float16)w[(size_t)c * kk + ky * 5 + 2 * d], (_Float16)0.0f};
+                            if (2 * d + 1 < 5) h[1] = (_Float16)w[(size_t)c * kk + ky * 5 + 2 * d + 1];
+                            uint32_t u;
+                            memcpy(&u, h, 4);
+                            dp[(size_t)(ky * 3 + d) * B.ce + c] = u;
+                        }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp, dp));
             }
         }
@@ -407,6 +405,16 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
+            if (tail_enabled && i >= 12 && i <= 14 && B.cs == 48) {
+                std::vector<_Float16> wrt((size_t)B.ce * 48), wet((size_t)48 * B.ce);
+                for (int c = 0; c < B.ce; ++c)
+                    for (int j = 0; j < 48; ++j) {
+                        wrt[(size_t)c * 48 + j] = (_Float16)wr[(size_t)j * B.ce + c];
+                        wet[(size_t)j * B.ce + c] = (_Float16)we[(size_t)c * B.cs + j];
+                    }
+                TRY_OR_FREE(dev_upload(bb, &B.t_wr, wrt));
+                TRY_OR_FREE(dev_upload(bb, &B.t_we, wet));
+            }
             TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
             TRY_OR_FREE(dev_upload(bb, &B.se_wep, wep));
             std::vector<float> brs(48, 0.f);
@@ -520,11 +528,11 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TAKE(b, FEAT, "head.bias");
         TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
     }
-    if (tail_enabled && bb->blk[12].exp_frag && bb->blk[13].exp_frag && bb->blk[14].exp_frag) {
+    if (tail_enabled && bb->blk[12].exp_frag && bb->blk[13].exp_frag && bb->blk[14].exp_frag && bb->blk[12].t_wr) {
         std::vector<TailBlock> tab(3);
         for (int j = 0; j < 3; ++j) {
             const BlockW& B = bb->blk[12 + j];
-            tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.se_wrp, B.se_br, B.se_wep, B.se_be, B.t_wproj, B.project.b};
+            tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr, B.se_br, B.t_we, B.se_be, B.t_wproj, B.project.b};
         }
         TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
     }
@@ -650,12 +658,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (i == 12 && bb->tail_tab) {
             // blocks 12..14 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
             if (!bb->keep) {
-                TailArgs ta{x, y, n, 3, bb->tail_tab, nullptr, nullptr};
+                TailArgs ta{x, y, n, 3, bb->tail_tab, nullptr, nullptr, nullptr};
                 STEP("b12-14.tail", "tail7", launch_tail7(ta, st));
                 _Float16* t = x; x = y; y = t;
             } else {
                 for (int j = 0; j < 3; ++j) {   // block at a time so every intermediate tensor can be read back
-                    TailArgs ta{x, y, n, 1, bb->tail_tab + j, ws.dwbuf, ws.gate};
+                    TailArgs ta{x, y, n, 1, bb->tail_tab + j, ws.dwbuf, ws.gate, ws.pool_part};
                     snprintf(nm, sizeof nm, "b%d.tail", 12 + j);
                     STEP(nm, "tail7", launch_tail7(ta, st));
                     int r;
@@ -665,6 +673,8 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                     if ((r = save_act(bb, nm, ws.gate, (size_t)n * bb->blk[12 + j].ce, false, st))) return r;
                     snprintf(nm, sizeof nm, "b%d.out", 12 + j);
                     if ((r = save_act(bb, nm, y, (size_t)n * 49 * 192, true, st))) return r;
+                    snprintf(nm, sizeof nm, "b%d.clk", 12 + j);
+                    if ((r = save_act(bb, nm, ws.pool_part, (size_t)n * 8, false, st))) return r;
                     _Float16* t = x; x = y; y = t;
                 }
             }
