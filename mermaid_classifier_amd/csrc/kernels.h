@@ -48,7 +48,8 @@ struct MbArgs {
     int wl_off, red_off, lds_bytes, wlds, wfr_off;
 };
 
-// One 7x7 MBConv block (192 -> 1152 -> 192, k5 s1, skip) packed for tail7_kernel
+// One 7x7 MBConv block (192 -> 1152 -> cout, stride 1) packed for tail7_kernel.  A 3x3 depthwise (b15) is
+// stored as a 5x5 with a zero outer ring (TF-same pad 1 == pad 2 of the embedded kernel).
 struct TailBlock {
     const _Float16* wexp;   // [72][6][64][8] expand weights, MFMA fragment order
     const float* bexp;      // [1152]
@@ -58,12 +59,14 @@ struct TailBlock {
     const float* br;        // [48]
     const _Float16* we_t;   // [48][1152] excite FC, k-major
     const float* be;        // [1152]
-    const _Float16* wproj;  // [12][36][64][8] project weights, MFMA fragment order
-    const float* bproj;     // [192]
+    const _Float16* wproj;  // [cout/16][36][64][8] project weights, MFMA fragment order
+    const float* bproj;     // [cout]
+    int cout;               // 192 (skip connection, b12..b14) or 320 (b15, no skip; must be the last block)
+    int reserved;
 };
 struct TailArgs {
     const _Float16* X;      // [B][49][192]
-    _Float16* Y;            // [B][49][192]
+    _Float16* Y;            // [B][49][cout of the last block]
     int B, nblk;
     const TailBlock* blk;   // device table, nblk consecutive rows
     _Float16* dbg_dw;       // optional [B][49][1152]: depthwise output of the last block run (nblk == 1)

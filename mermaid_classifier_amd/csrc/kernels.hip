@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 #define T7_CE 1152
 #define T7_XS 400                                    // X row stride, bytes
 #define T7_ES 2320                                   // ED row stride, bytes (580 dwords = 4 mod 64 banks)
+#define T7_YS 656                                    // row stride of b15's 320-channel output (parked in ED)
 #define T7_OFF_X (T7_PIX * T7_ES)
 #define T7_OFF_POOL (T7_OFF_X + T7_PIX * T7_XS)
 #define T7_OFF_GATE (T7_OFF_POOL + T7_CE * 4)
@@ -1390,6 +1391,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         }
     }
     __syncthreads();
+    bool out_wide = false;
 #pragma unroll 1
     for (int nb = 0; nb < a.nblk; ++nb) {
         // One table row via scalar loads.  Pointers that come out of memory are "flat" to the compiler; the casts
@@ -1664,19 +1666,23 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int j = 0; j < 4; ++j) o[j] = sigmoid_f(acc[j]);
             *reinterpret_cast<f4*>(gate + 4 * tid) = o;
         }
-        // project: bias and the first four k-steps of weight fragments are requested before the gate pass
-        const bool two = wave < 4;
-        const int nf0 = two ? 2 * wave : 4 + wave;
-        const int nf1 = two ? nf0 + 1 : nf0;
-        const f4 pb0 = gload<f4>(W.bproj, (unsigned)(16 * nf0 + 4 * q) * 4u);
-        const f4 pb1 = gload<f4>(W.bproj, (unsigned)(16 * nf1 + 4 * q) * 4u);
-        const unsigned wo0 = (unsigned)((nf0 * 36 * 64 + lane) * 16);
-        const unsigned wo1 = (unsigned)((nf1 * 36 * 64 + lane) * 16);
-        h8 wa0[4], wa1[4];
+        // project: bias and the first four k-steps of weight fragments are requested before the gate pass.
+        // Output fragments (16 channels) per wave: 192 outputs = 12 fragments -> waves 0..3 take 2, waves 4..7 take 1;
+        // 320 outputs (b15) = 20 fragments -> 3 and 2.  Every SIMD hosts one wave of each kind: equal MFMA work.
+        const bool wide = Wt.cout == 320;
+        const bool lowh = wave < 4;
+        const int nfn = wide ? (lowh ? 3 : 2) : (lowh ? 2 : 1);
+        const int nf0 = wide ? (lowh ? 3 * wave : 2 * wave + 4) : (lowh ? 2 * wave : wave + 4);
+        f4 pbias[3];
+        unsigned wo[3];
+        h8 wa[3][4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            wa0[d] = gload<h8>(W.wproj, wo0 + (unsigned)(d * 1024));
-            wa1[d] = gload<h8>(W.wproj, wo1 + (unsigned)(d * 1024));
+        for (int i = 0; i < 3; ++i) {
+            const int nf = nf0 + (i < nfn ? i : 0);   // surplus slots alias fragment nf0 (loaded, never used)
+            pbias[i] = gload<f4>(W.bproj, (unsigned)(16 * nf + 4 * q) * 4u);
+            wo[i] = (unsigned)((nf * 36 * 64 + lane) * 16);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) wa[i][d] = gload<h8>(W.wproj, wo[i] + (unsigned)(d * 1024));
         }
         T7_BAR();
         T7_TICK();
@@ -1699,17 +1705,19 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         }
         T7_BAR();
         T7_TICK();
-        // ---------------- project + bias + residual -> X in place ----------------
+        // ---------------- project + bias (+ residual) ----------------
         {
-            f4 acc0[4], acc1[4];
+            f4 acc[3][4];
 #pragma unroll
-            for (int pf = 0; pf < 4; ++pf) { acc0[pf] = pb0; acc1[pf] = pb1; }
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) acc[i][pf] = pbias[i];
             const unsigned char* bxp[4];
 #pragma unroll
             for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * T7_ES + 16 * q;
-            // NF = output fragments of this wave (2 for waves 0..3, 1 for waves 4..7): two straight-line loops instead of
-            // wave-uniform branches inside one.  Pixel fragments are read one k-step ahead of the MFMAs that use them,
-            // weight fragments four k-steps ahead.  The K order is part of the result: same for every workgroup.
+            // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside
+            // one.  Pixel fragments are read one k-step ahead of the MFMAs that use them, weight fragments four
+            // k-steps ahead.  The K order is part of the result: same for every workgroup.
             auto k_loop = [&](auto nf_tag) {
                 constexpr int NF = decltype(nf_tag)::value;
                 h8 bx[4], bn[4];
@@ -1723,41 +1731,57 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                         const int kn = ks + 1 < 36 ? ks + 1 : 35;   // last step re-reads itself (unused)
 #pragma unroll
                         for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
-                        const h8 w0 = wa0[d], w1 = wa1[d];
-                        const int kw = ks + 4 < 36 ? ks + 4 : 35;   // the last four prefetches re-read step 35 (unused)
-                        wa0[d] = gload<h8>(W.wproj, wo0 + (unsigned)(kw * 1024));
-                        if (NF == 2) wa1[d] = gload<h8>(W.wproj, wo1 + (unsigned)(kw * 1024));
+                        h8 w[NF];
 #pragma unroll
-                        for (int pf = 0; pf < 4; ++pf)
-                            acc0[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, bx[pf], acc0[pf], 0, 0, 0);
-                        if (NF == 2) {
+                        for (int i = 0; i < NF; ++i) w[i] = wa[i][d];
+                        const int kw = ks + 4 < 36 ? ks + 4 : 35;   // the last four prefetches re-read step 35 (unused)
+#pragma unroll
+                        for (int i = 0; i < NF; ++i) wa[i][d] = gload<h8>(W.wproj, wo[i] + (unsigned)(kw * 1024));
+#pragma unroll
+                        for (int i = 0; i < NF; ++i)
 #pragma unroll
                             for (int pf = 0; pf < 4; ++pf)
-                                acc1[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, bx[pf], acc1[pf], 0, 0, 0);
-                        }
+                                acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], bx[pf], acc[i][pf], 0, 0, 0);
 #pragma unroll
                         for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
                     }
                 }
             };
-            if (two) k_loop(std::integral_constant<int, 2>{});
+            if (nfn == 3) k_loop(std::integral_constant<int, 3>{});
+            else if (nfn == 2) k_loop(std::integral_constant<int, 2>{});
             else k_loop(std::integral_constant<int, 1>{});
+            if (!wide) {   // 192 outputs, skip connection: X <- fp16(acc + X), in place (each lane owns its elements)
 #pragma unroll
-            for (int pf = 0; pf < 4; ++pf) {
-                if (16 * pf + m >= T7_PIX) continue;
+                for (int pf = 0; pf < 4; ++pf) {
+                    if (16 * pf + m >= T7_PIX) continue;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i == 1 && !two) continue;
-                    const int nf = i ? nf1 : nf0;
-                    h4* px = reinterpret_cast<h4*>(XL + (16 * pf + m) * T7_XS + (16 * nf + 4 * q) * 2);
-                    const h4 r = *px;
-                    h4 o;
+                    for (int i = 0; i < 2; ++i) {
+                        if (i >= nfn) continue;
+                        h4* px = reinterpret_cast<h4*>(XL + (16 * pf + m) * T7_XS + (16 * (nf0 + i) + 4 * q) * 2);
+                        const h4 r = *px;
+                        h4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)((i ? acc1[pf][j] : acc0[pf][j]) + (float)r[j]);
-                    *px = o;
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[i][pf][j] + (float)r[j]);
+                        *px = o;
+                    }
+                }
+            } else {       // b15: 320 outputs, no skip; the result replaces ED (all reads of ED are done after the barrier)
+                T7_BAR();
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) {
+                    if (16 * pf + m >= T7_PIX) continue;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (i >= nfn) continue;
+                        h4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[i][pf][j];
+                        *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_YS + (16 * (nf0 + i) + 4 * q) * 2) = o;
+                    }
                 }
             }
         }
+        out_wide = wide;
         T7_BAR();
         T7_TICK();
 #undef T7_TICK
@@ -1765,16 +1789,22 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int i = 0; i < 6; ++i) a.dbg_clk[(size_t)b * 8 + i] = (float)(tk[i + 1] - tk[i]);
         }
     }
-    {
+    if (!out_wide) {
         const int tid = tid0;
         _Float16* yg = a.Y + (size_t)b * T7_PIX * T7_C;
         for (int e = tid; e < T7_PIX * 24; e += 512) {
             const int pix = e / 24, p16 = e - pix * 24;
             *reinterpret_cast<h8*>(yg + pix * T7_C + p16 * 8) = *reinterpret_cast<const h8*>(XL + pix * T7_XS + p16 * 16);
         }
+    } else {
+        const int tid = tid0;
+        _Float16* yg = a.Y + (size_t)b * T7_PIX * 320;
+        for (int e = tid; e < T7_PIX * 40; e += 512) {
+            const int pix = e / 40, p16 = e - pix * 40;
+            *reinterpret_cast<h8*>(yg + pix * 320 + p16 * 8) = *reinterpret_cast<const h8*>(ED + pix * T7_YS + p16 * 16);
+        }
     }
 }
-
 // ---------------------------------------------------------------------------------------------
 // Fused stem + block-0 depthwise: u8 patch -> [stem conv3x3s2 + bias + SiLU] -> LDS -> [depthwise 3x3 s1 +
 // bias + SiLU] -> fp16 NHWC (112x112x32) + squeeze-excite partial sums.  The 112x112x32 stem output (the
@@ -2229,7 +2259,7 @@ int launch_mbconv_d(const MbArgs& a, hipStream_t st)
 
 int launch_tail7(const TailArgs& a, hipStream_t st)
 {
-    if (a.nblk < 1 || a.nblk > 3 || a.B < 1) return -9;
+    if (a.nblk < 1 || a.nblk > 4 || a.B < 1) return -9;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel),

@@ -365,15 +365,20 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if (tail_enabled && i >= 12 && i <= 14) {
+            if (tail_enabled && i >= 12 && i <= 15) {
                 // taps of tail7_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
+                const int ring = (5 - B.d.k) / 2;   // a 3x3 kernel (b15) sits in the middle of a 5x5 of zeros
+                auto tap = [&](int c, int ky, int kx) -> _Float16 {
+                    const int y = ky - ring, x = kx - ring;
+                    if (kx >= 5 || y < 0 || x < 0 || y >= B.d.k || x >= B.d.k) return (_Float16)0.0f;
+                    return (_Float16)w[(size_t)c * kk + y * B.d.k + x];
+                };
                 for (int c = 0; c < B.ce; ++c)
                     for (int ky = 0; ky < 5; ++ky)
                         for (int d = 0; d < 3; ++d) {
-                            _Float16 h[2] = {(_Float16)w[(size_t)c * kk + ky * 5 + 2 * d], (_Float16)0.0f};
-                            if (2 * d + 1 < 5) h[1] = (_Float16)w[(size_t)c * kk + ky * 5 + 2 * d + 1];
+                            _Float16 h[2] = {tap(c, ky, 2 * d), tap(c, ky, 2 * d + 1)};
                             uint32_t u;
                             memcpy(&u, h, 4);
                             dp[(size_t)(ky * 3 + d) * B.ce + c] = u;
@@ -405,7 +410,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
-            if (tail_enabled && i >= 12 && i <= 14 && B.cs == 48) {
+            if (tail_enabled && i >= 12 && i <= 15 && B.cs == 48) {
                 std::vector<_Float16> wrt((size_t)B.ce * 48), wet((size_t)48 * B.ce);
                 for (int c = 0; c < B.ce; ++c)
                     for (int j = 0; j < 48; ++j) {
@@ -427,7 +432,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
             TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
-            if (tail_enabled && i >= 12 && i <= 14) {
+            if (tail_enabled && i >= 12 && i <= 15) {
                 // plain MFMA fragment order [cout/16][ce/32][64 lanes][8]: lane (q*16 + m) holds W[16nf + m][32ks + 8q ..+8]
                 const int ks32 = B.ce / 32;
                 std::vector<_Float16> wf((size_t)B.d.cout * B.ce);
@@ -528,13 +533,21 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TAKE(b, FEAT, "head.bias");
         TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
     }
-    if (tail_enabled && bb->blk[12].exp_frag && bb->blk[13].exp_frag && bb->blk[14].exp_frag && bb->blk[12].t_wr) {
-        std::vector<TailBlock> tab(3);
-        for (int j = 0; j < 3; ++j) {
-            const BlockW& B = bb->blk[12 + j];
-            tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr, B.se_br, B.t_we, B.se_be, B.t_wproj, B.project.b};
+    if (tail_enabled) {
+        bool ok = true;
+        for (int i = 12; i <= 15; ++i) {
+            const BlockW& B = bb->blk[i];
+            ok = ok && B.exp_frag && B.t_wr && B.t_dwp && B.t_wproj && B.H == 7 && B.d.s == 1 && B.d.cin == 192 && B.ce == 1152;
         }
-        TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
+        if (ok) {
+            std::vector<TailBlock> tab(4);
+            for (int j = 0; j < 4; ++j) {
+                const BlockW& B = bb->blk[12 + j];
+                tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr, B.se_br, B.t_we, B.se_be, B.t_wproj, B.project.b,
+                                   B.d.cout, 0};
+            }
+            TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
+        }
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -656,13 +669,13 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
     }
     for (int i = 0; i < 16; ++i) {
         if (i == 12 && bb->tail_tab) {
-            // blocks 12..14 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
+            // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
             if (!bb->keep) {
-                TailArgs ta{x, y, n, 3, bb->tail_tab, nullptr, nullptr, nullptr};
-                STEP("b12-14.tail", "tail7", launch_tail7(ta, st));
+                TailArgs ta{x, y, n, 4, bb->tail_tab, nullptr, nullptr, nullptr};
+                STEP("b12-15.tail", "tail7", launch_tail7(ta, st));
                 _Float16* t = x; x = y; y = t;
             } else {
-                for (int j = 0; j < 3; ++j) {   // block at a time so every intermediate tensor can be read back
+                for (int j = 0; j < 4; ++j) {   // block at a time so every intermediate tensor can be read back
                     TailArgs ta{x, y, n, 1, bb->tail_tab + j, ws.dwbuf, ws.gate, ws.pool_part};
                     snprintf(nm, sizeof nm, "b%d.tail", 12 + j);
                     STEP(nm, "tail7", launch_tail7(ta, st));
@@ -672,13 +685,13 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                     snprintf(nm, sizeof nm, "b%d.gate", 12 + j);
                     if ((r = save_act(bb, nm, ws.gate, (size_t)n * bb->blk[12 + j].ce, false, st))) return r;
                     snprintf(nm, sizeof nm, "b%d.out", 12 + j);
-                    if ((r = save_act(bb, nm, y, (size_t)n * 49 * 192, true, st))) return r;
+                    if ((r = save_act(bb, nm, y, (size_t)n * 49 * bb->blk[12 + j].d.cout, true, st))) return r;
                     snprintf(nm, sizeof nm, "b%d.clk", 12 + j);
                     if ((r = save_act(bb, nm, ws.pool_part, (size_t)n * 8, false, st))) return r;
                     _Float16* t = x; x = y; y = t;
                 }
             }
-            i = 14;
+            i = 15;
             continue;
         }
         BlockW& B = bb->blk[i];

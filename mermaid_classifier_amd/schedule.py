@@ -44,10 +44,10 @@ def b0_launches(batch: int) -> List[Launch]:
         out.append(Launch(f"b{i}.project", "project", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2,
                           2 * m_out * ce * cout))
         h = ho
-    # blocks 12..14 chained in one launch (tail7_kernel): only the 7x7x192 block input/output and the weights move
-    tail = [l for l in out if l.name.split(".")[0] in ("b12", "b13", "b14") and l.kind in ("mbconv", "se", "project")]
-    w_bytes = sum(1152 * 192 * 2 * 2 + 30 * 1152 * 4 + 2 * 48 * 1152 * 4 for _ in range(3))
-    out.append(Launch("b12-14.tail", "tail", 2 * batch * 49 * 192 * 2 + w_bytes, sum(l.flops for l in tail)))
+    # blocks 12..15 chained in one launch (tail7_kernel): only the 7x7 block input/output and the weights move
+    tail = [l for l in out if l.name.split(".")[0] in ("b12", "b13", "b14", "b15") and l.kind in ("mbconv", "se", "project")]
+    w_bytes = 4 * (1152 * 192 * 2 + 15 * 1152 * 4 + 2 * 48 * 1152 * 2) + (3 * 192 + 320) * 1152 * 2
+    out.append(Launch("b12-15.tail", "tail", batch * 49 * (192 + 320) * 2 + w_bytes, sum(l.flops for l in tail)))
     out.append(Launch("head", "head", batch * h * h * 320 * 2 + batch * FEATURE_DIM * 4 + FEATURE_DIM * 320 * 2,
                       2 * batch * h * h * 320 * FEATURE_DIM))
     return out

@@ -22,7 +22,7 @@ def main():
         bb.extract(p, out=f)
     torch.cuda.synchronize()
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
-    for blk in (12, 13, 14):
+    for blk in (12, 13, 14, 15):
         clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :6]
         med = np.median(clk, axis=0)
         print(f"b{blk}: " + "  ".join(f"{nm} {c:8.0f}" for nm, c in zip(names, med)) + f"   total {med.sum():8.0f} cycles")
