@@ -146,7 +146,7 @@ def main():
     if rank == 0:
         value = world * BATCH * args.steps / elapsed
         # per-kernel durations, HIP events on the launch stream, same resident workload
-        per_kernel = defaultdict(lambda: [0.0, 0, 0])  # ms, launches, bytes
+        per_kernel = defaultdict(lambda: [0.0, 0, 0, 0])  # ms, launches, algorithmic bytes, algorithmic flops
         sub = -(-BATCH // bb.lanes)   # each launch of the schedule covers one lane's sub-batch
         alg = {l.name: l for l in schedule.b0_launches(sub)}
         launched = []
@@ -158,8 +158,14 @@ def main():
                 e[0] += ms
                 e[1] += 1
                 e[2] += alg[layer].bytes
-        dom, (ms, launches, nbytes) = max(per_kernel.items(), key=lambda kv: kv[1][0])
-        achieved = nbytes / (ms * 1e-3) / 1e9
+                e[3] += alg[layer].flops
+        dom, (ms, launches, nbytes, nflops) = max(per_kernel.items(), key=lambda kv: kv[1][0])
+        # which roof bounds the dominant kernel: the one its algorithmic work needs longer on
+        mfma_bound = nflops / (schedule.MFMA_F16_PEAK_TFLOPS * 1e12) > nbytes / (schedule.HBM_PEAK_GBS * 1e9)
+        if mfma_bound:
+            achieved, peak, unit = nflops / (ms * 1e-3) / 1e12, schedule.MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = nbytes / (ms * 1e-3) / 1e9, schedule.HBM_PEAK_GBS, "GB/s"
         tot = schedule.totals(BATCH, launched)
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profiles.py), if present
@@ -174,11 +180,11 @@ def main():
                 traffic = sum(h["read_bytes_per_launch"] + h["write_bytes_per_launch"] for h in hits) / len(hits)
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": schedule.HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / schedule.HBM_PEAK_GBS, "traffic": traffic,
+        roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
+                    "frac": achieved / peak, "traffic": traffic,
                     "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
                     "patches_per_launch": sub,
-                    "alg_bytes_per_launch": nbytes / launches,
+                    "alg_bytes_per_launch": nbytes / launches, "alg_flops_per_launch": nflops / launches,
                     "whole_net": {"alg_GB_per_step": tot["bytes"] / 1e9,
                                   "hbm_frac_at_value": tot["bytes_per_patch"] * value / 1e9 / schedule.HBM_PEAK_GBS,
                                   "mfma_frac_at_value": tot["flops_per_patch"] * value / 1e12 / schedule.MFMA_F16_PEAK_TFLOPS}}

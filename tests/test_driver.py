@@ -1,0 +1,131 @@
+"""Per-source driver: bookkeeping semantics of the reference loop
+(scripts/build_feature_bucket.py:691-823) over cross-image GPU batches."""
+import csv
+import io
+import json
+
+import numpy as np
+import pytest
+
+from mermaid_classifier_amd import driver
+from mermaid_classifier_amd.spacer_shim import DataLocation, ImageFeatures, PointFeatures
+
+
+class _FakeBatched:
+    """Duck-typed BatchedExtractor for the host-logic test: feature = [row, col, mean pixel]."""
+    feature_dim = 3
+
+    def __init__(self, explode_on=None):
+        self.calls = []
+        self.explode_on = explode_on
+
+    def extract_image_features(self, images, rowcols_per_image):
+        self.calls.append(len(images))
+        out = []
+        for im, rc in zip(images, rowcols_per_image):
+            if self.explode_on is not None and int(im[0, 0, 0]) == self.explode_on:
+                raise RuntimeError("device lost")
+            pfs = [PointFeatures(r, c, [float(r), float(c), float(im.mean())]) for r, c in rc]
+            out.append(ImageFeatures(pfs, True, 3, len(pfs)))
+        return out
+
+
+def _img(v, h=300, w=320):
+    return np.full((h, w, 3), v, np.uint8)
+
+
+def test_process_source_bookkeeping(tmp_path):
+    images = {
+        "0003": [(10, 10), (200, 300)],
+        "0001": [(5, 5)],
+        "0002": [],                       # no points -> skipped(no_rowcols)
+        "0004": [(299, 319)],             # already extracted -> skipped(exists)
+        "0005": [(400, 10)],              # point outside the image -> failed(ValueError), isolated
+        "0006": [(1, 1)],                 # load error -> failed(OSError)
+        "0007": [(7, 7)],
+    }
+    pixels = {"0001": 1, "0003": 3, "0005": 5, "0007": 7}
+
+    def load(image_id):
+        if image_id == "0006":
+            raise OSError("truncated jpeg")
+        return _img(pixels[image_id])
+
+    root = str(tmp_path)
+    store = driver.fs_store(root, "17")
+    store("0004", ImageFeatures([PointFeatures(299, 319, [0.0, 0.0, 0.0])], True, 3, 1))
+    assert driver.fs_existing(root, "17") == {"0004"}
+    prog, errf = io.StringIO(), io.StringIO()
+    ew = csv.writer(errf)
+    ex = _FakeBatched()
+    c = driver.process_source(source_id="17", images=images, load_image=load, store_features=store, extractor=ex,
+                              existing=driver.fs_existing(root, "17"), progress_writer=prog, error_writer=ew,
+                              prefetch=2, group_images=2)
+    assert (c.images_ok, c.images_skipped, c.images_failed, c.sources_done) == (3, 2, 2, 1)
+    assert ex.calls == [2, 1]                                    # grouped passes, not one per image
+    recs = [json.loads(l) for l in prog.getvalue().splitlines()]
+    by = {r["image_id"]: r for r in recs}
+    assert by["0002"]["outcome"] == "skipped" and by["0002"]["reason"] == "no_rowcols"
+    assert by["0004"]["outcome"] == "skipped" and by["0004"]["reason"] == "exists"
+    assert by["0005"]["outcome"] == "failed" and by["0005"]["error_type"] == "ValueError"
+    assert by["0006"]["outcome"] == "failed" and by["0006"]["error_type"] == "OSError"
+    assert all(set(r) >= {"ts", "source_id", "image_id", "outcome"} and r["source_id"] == "17" for r in recs)
+    rows = list(csv.reader(io.StringIO(errf.getvalue())))
+    assert [r[2] for r in rows] == ["0005", "0006"] and rows[0][3] == "ValueError" and "outside" in rows[0][4]
+    assert driver.fs_existing(root, "17") == {"0001", "0003", "0004", "0007"}
+    f3 = ImageFeatures.load(DataLocation("filesystem", str(tmp_path / driver.feature_key("17", "0003"))))
+    np.testing.assert_allclose(f3.get_array((200, 300)), [200.0, 300.0, 3.0])
+    # resume: a second run touches nothing
+    ex2 = _FakeBatched()
+    c2 = driver.process_source(source_id="17", images={k: v for k, v in images.items() if k not in ("0005", "0006")},
+                               load_image=load, store_features=store, extractor=ex2, existing=driver.fs_existing(root, "17"))
+    assert (c2.images_ok, c2.images_skipped, c2.images_failed) == (0, 5, 0) and ex2.calls == []
+
+
+def test_group_failure_and_dry_run(tmp_path):
+    images = {"a": [(1, 1)], "b": [(2, 2)], "c": [(3, 3)]}
+    load = lambda i: _img({"a": 1, "b": 2, "c": 3}[i])          # noqa: E731
+    stored = {}
+    ex = _FakeBatched(explode_on=2)
+    c = driver.process_source(source_id="1", images=images, load_image=load, store_features=stored.__setitem__,
+                              extractor=ex, group_images=2)
+    # group (a, b) dies on the device -> both failed; c is unaffected
+    assert (c.images_ok, c.images_failed) == (1, 2) and set(stored) == {"c"}
+    c = driver.process_source(source_id="1", images=images, load_image=load, store_features=stored.__setitem__,
+                              extractor=_FakeBatched(), dry_run=True)
+    assert c.images_ok == 3 and set(stored) == {"c"}
+    assert driver.process_source(source_id="2", images={}, load_image=load, store_features=stored.__setitem__,
+                                 extractor=_FakeBatched()).sources_skipped == 1
+
+
+def test_open_logs_header(tmp_path):
+    pf, ew, close = driver.open_logs(str(tmp_path / "p.jsonl"), str(tmp_path / "e.csv"))
+    driver.record_failure(ew, "1", "2", "ValueError", "x")
+    driver.record_progress(pf, "1", "2", "failed", error_type="ValueError")
+    close()
+    rows = list(csv.reader(open(tmp_path / "e.csv")))
+    assert rows[0] == ["ts", "source_id", "image_id", "error_type", "error_msg"] and rows[1][1:] == ["1", "2", "ValueError", "x"]
+
+
+@pytest.mark.gpu
+def test_driver_on_gpu_matches_direct_extraction(tmp_path, synth_sd):
+    from mermaid_classifier_amd.backbone import Backbone
+    from mermaid_classifier_amd.pipeline import BatchedExtractor
+    from oracle import pyspacer_ref
+    rng = np.random.default_rng(5)
+    imgs = {f"{i:03d}": rng.integers(0, 255, (400 + 16 * i, 500, 3), dtype=np.uint8) for i in range(5)}
+    pts = {k: [(int(rng.integers(0, v.shape[0])), int(rng.integers(0, v.shape[1]))) for _ in range(7)] for k, v in imgs.items()}
+    pts["003"].append((10_000, 3))                                # this image fails validation, the others are extracted
+    bb = Backbone(synth_sd, device=0, max_batch=64)
+    try:
+        c = driver.process_source(source_id="9", images=pts, load_image=imgs.__getitem__, store_features=driver.fs_store(str(tmp_path), "9"),
+                                  extractor=BatchedExtractor(bb, batch_patches=64), group_images=3)
+        assert (c.images_ok, c.images_failed) == (4, 1)
+        for k in ("000", "004"):
+            got = ImageFeatures.load(DataLocation("filesystem", str(tmp_path / driver.feature_key("9", k))))
+            patches = pyspacer_ref.crop_patches(imgs[k], pts[k])
+            want = bb.extract(np.stack(patches))
+            for (r, cc), row in zip(pts[k], want):
+                np.testing.assert_array_equal(got.get_array((r, cc)), row.astype(np.float32))
+    finally:
+        bb.close()
