@@ -48,12 +48,11 @@ struct MbArgs {
     int wl_off, red_off, lds_bytes, wlds, wfr_off;
 };
 
-// One 7x7 MBConv block (192 -> 1152 -> cout, stride 1) packed for tail7_kernel.  A 3x3 depthwise (b15) is
-// stored as a 5x5 with a zero outer ring (TF-same pad 1 == pad 2 of the embedded kernel).
+// One 7x7 MBConv block (192 -> 1152 -> cout, depthwise 5x5 or 3x3, stride 1) packed for tail7_kernel.
 struct TailBlock {
     const _Float16* wexp;   // [72][6][64][8] expand weights, MFMA fragment order
     const float* bexp;      // [1152]
-    const uint32_t* dwp;    // [15][1152] depthwise taps as fp16 pairs: row ky = (k0,k1), (k2,k3), (k4,0)
+    const uint32_t* dwp;    // [15][1152] depthwise taps as fp16 pairs: slot 3*ky + d; 5x5: (k0,k1),(k2,k3),(k4,0); 3x3: (k0,k1),(k2,0),0
     const float* bdw;       // [1152]
     const _Float16* wr_t;   // [1152][48] squeeze FC, channel-major (unscaled: 1/(49*log2e) is applied in fp32)
     const float* br;        // [48]
@@ -62,7 +61,7 @@ struct TailBlock {
     const _Float16* wproj;  // [cout/16][36][64][8] project weights, MFMA fragment order
     const float* bproj;     // [cout]
     int cout;               // 192 (skip connection, b12..b14) or 320 (b15, no skip; must be the last block)
-    int reserved;
+    int ks;                 // depthwise kernel size: 5 or 3
 };
 struct TailArgs {
     const _Float16* X;      // [B][49][192]

@@ -1418,26 +1418,17 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll
         for (int pf = 0; pf < 4; ++pf) pixc[pf] = (16 * pf + m) < T7_PIX ? (16 * pf + m) : (T7_PIX - 1);
         // Depthwise taps of this thread's first channel: issued now, they arrive while the expand phase computes.
-        // (15 dwords per channel: kernel row ky = (k0,k1), (k2,k3), (k4,0) as fp16 pairs.)
+        // (3 dwords per kernel row ky: (k0,k1), (k2,k3), (k4,0) as fp16 pairs; a 3x3 kernel fills rows 0..2 with
+        // (k0,k1), (k2,0), 0.)
+        const bool ks3 = Wt.ks == 3;
         uint32_t rawA[15], rawB[15];
         float biasA, biasB;
 #pragma unroll
-        for (int i = 0; i < 15; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + tid) * 4u);
+        for (int i = 0; i < 15; ++i) {
+            rawA[i] = 0u;
+            if (i < 9 || !ks3) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + tid) * 4u);
+        }
         biasA = gload<float>(W.bdw, (unsigned)tid * 4u);
-        // the six tap pairs of a kernel row: output x even uses (k0,k1)(k2,k3)(k4,0) on pixel pairs starting at x-2,
-        // output x odd uses (0,k0)(k1,k2)(k3,k4) on pairs starting at x-3 -- the same values mbconv_d_kernel keeps in LDS
-        auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[30]) {
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
-                wp[(ky * 2 + 0) * 3 + 0] = r0;
-                wp[(ky * 2 + 0) * 3 + 1] = r1;
-                wp[(ky * 2 + 0) * 3 + 2] = r2;
-                wp[(ky * 2 + 1) * 3 + 0] = r0 << 16;
-                wp[(ky * 2 + 1) * 3 + 1] = __builtin_amdgcn_alignbit(r1, r0, 16);
-                wp[(ky * 2 + 1) * 3 + 2] = __builtin_amdgcn_alignbit(r2, r1, 16);
-            }
-        };
         // ---------------- expand: ED = silu(X . Wexp^T + b) ----------------
         {
             h8 xb[4][6];
@@ -1486,117 +1477,75 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         }
         T7_BAR();
         T7_TICK();
-        // ---------------- depthwise 5x5 + silu, in place; pooled sums ----------------
-        // one full round: thread = one expanded channel c, all 49 pixels
-        auto dw_round = [&](int c, const uint32_t (&raw)[15], float bias) {
-            uint32_t wp[30];
-            tap_pairs(raw, wp);
-            unsigned char* col = ED + 2 * c;
-            uint32_t P[28];
-#pragma unroll
-            for (int y = 0; y < 7; ++y)
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp) * T7_ES);
-                    uint32_t hi = 0;
-                    if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp + 1) * T7_ES);
-                    P[y * 4 + pp] = lo | (hi << 16);
-                }
-            float psum = 0.f;
-#pragma unroll
-            for (int oy = 0; oy < 7; ++oy) {
-                // the seven outputs of a row advance together (ox innermost): consecutive v_dot2c go to different
-                // accumulators, so no dependent-issue stalls
-                float acc[7];
-#pragma unroll
-                for (int ox = 0; ox < 7; ++ox) acc[ox] = bias;
-#pragma unroll
-                for (int ky = 0; ky < 5; ++ky) {
-                    const int iy = oy - 2 + ky;
-                    if (iy < 0 || iy >= 7) continue;
-#pragma unroll
-                    for (int ip = 0; ip < 3; ++ip)
-#pragma unroll
-                        for (int ox = 0; ox < 7; ++ox) {
-                            const int xpc = (ox >> 1) - 1 + ip;
-                            if (xpc < 0 || xpc > 3) continue;
-                            acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
-                                                             *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * 3 + ip]),
-                                                             acc[ox], false);
-                        }
-                }
-#pragma unroll
-                for (int ox = 0; ox < 7; ++ox) {
-                    const float y = silu_scaled(acc[ox]);
-                    psum += y;
-                    *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
-                }
-            }
-            pooled[c] = psum;
-        };
-        // taps of the next round are requested before the current round computes
-#pragma unroll
-        for (int i = 0; i < 15; ++i) rawB[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 512 + tid) * 4u);
-        biasB = gload<float>(W.bdw, (unsigned)(512 + tid) * 4u);
-        dw_round(tid, rawA, biasA);
-        const int cl = tid & 127, p4 = tid >> 7, rb = 2 * p4;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 1024 + cl) * 4u);
-        biasA = gload<float>(W.bdw, (unsigned)(1024 + cl) * 4u);
-        dw_round(512 + tid, rawB, biasB);
-        // Squeeze FC weights (fp16, 36 x 8 bytes per thread): requested before the last quarter round, which is pure
-        // VALU/LDS work (earlier the two tap buffers leave no registers for them).
+        // ---------------- depthwise KSxKS (5 or 3) + silu, in place; pooled sums ----------------
+        // Pixels of a row are paired (x even, x+1); a v_dot2c does two taps.  KS = 5: output x even uses
+        // (k0,k1)(k2,k3)(k4,0) on the pairs from x-2, output x odd (0,k0)(k1,k2)(k3,k4) on the pairs from x-3 -- the
+        // values mbconv_d_kernel keeps in LDS.  KS = 3: x even (0,k0)(k1,k2) on the pairs from x-2, x odd (k0,k1)(k2,0)
+        // on the pairs from x-1.  The odd/even variants are derived from the raw row pairs by shifts.
         const bool fc1_thr = tid < 384;
         const int cr = tid / 12, j4 = tid - cr * 12;   // FC1: thread = 4 outputs j x channels cr, cr+32, ...
         u2v fw1[36];   // 4 fp16 weights each, consumed by v_fma_mix_f32 without conversion
-        {
-            const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)
+        auto dw_phase = [&](auto ks_tag) {
+            constexpr int KS = decltype(ks_tag)::value, R = KS / 2, NP = KS == 5 ? 3 : 2;
+            auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[2 * KS * NP]) {
 #pragma unroll
-            for (int i = 0; i < 36; ++i) fw1[i] = gload<u2v>(W.wr_t, (unsigned)(((32 * i + crl) * 48 + 4 * j4) * 2));
-        }
-        {
-            // Channels 1024..1151 (a quarter round) are shared by FOUR threads each so that all 8 waves stay busy:
-            // thread (channel, p) computes output rows 2p and 2p+1 from input rows 2p-2 .. 2p+3 (zeros outside the
-            // image).  In place needs every read of a channel before any write: barrier in between.
-            const int c = 1024 + cl;
-            uint32_t wpA[30];
-            tap_pairs(rawA, wpA);
-            unsigned char* col = ED + 2 * c;
-            uint32_t P[24];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int iy = rb - 2 + r;
-                const bool rok = iy >= 0 && iy < 7;
-                const unsigned char* rowp = col + (rok ? iy : 0) * (7 * T7_ES);
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * T7_ES);
-                    uint32_t hi = 0;
-                    if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * T7_ES);
-                    P[r * 4 + pp] = rok ? (lo | (hi << 16)) : 0u;
+                for (int ky = 0; ky < KS; ++ky) {
+                    const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                    if (KS == 5) {
+                        wp[(ky * 2 + 0) * NP + 0] = r0;
+                        wp[(ky * 2 + 0) * NP + 1] = r1;
+                        wp[(ky * 2 + 0) * NP + (NP - 1)] = r2;
+                        wp[(ky * 2 + 1) * NP + 0] = r0 << 16;
+                        wp[(ky * 2 + 1) * NP + 1] = __builtin_amdgcn_alignbit(r1, r0, 16);
+                        wp[(ky * 2 + 1) * NP + (NP - 1)] = __builtin_amdgcn_alignbit(r2, r1, 16);
+                    } else {
+                        wp[(ky * 2 + 0) * NP + 0] = r0 << 16;
+                        wp[(ky * 2 + 0) * NP + 1] = __builtin_amdgcn_alignbit(r1, r0, 16);
+                        wp[(ky * 2 + 1) * NP + 0] = r0;
+                        wp[(ky * 2 + 1) * NP + 1] = r1;
+                    }
                 }
-            }
-            T7_BAR();
-            float psum = 0.f;
+            };
+            // first pixel pair an output column reads
+            auto first_pair = [](int ox) { return (KS == 5 || !(ox & 1)) ? (ox >> 1) - 1 : (ox >> 1); };
+            // one full round: thread = one expanded channel c, all 49 pixels
+            auto dw_round = [&](int c, const uint32_t (&raw)[15], float bias) {
+                uint32_t wp[2 * KS * NP];
+                tap_pairs(raw, wp);
+                unsigned char* col = ED + 2 * c;
+                uint32_t P[28];
 #pragma unroll
-            for (int ro = 0; ro < 2; ++ro) {
-                const int oy = rb + ro;
-                if (oy < 7) {
+                for (int y = 0; y < 7; ++y)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp) * T7_ES);
+                        uint32_t hi = 0;
+                        if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp + 1) * T7_ES);
+                        P[y * 4 + pp] = lo | (hi << 16);
+                    }
+                float psum = 0.f;
+#pragma unroll
+                for (int oy = 0; oy < 7; ++oy) {
+                    // the seven outputs of a row advance together (ox innermost): consecutive v_dot2c go to different
+                    // accumulators, so no dependent-issue stalls
                     float acc[7];
 #pragma unroll
-                    for (int ox = 0; ox < 7; ++ox) acc[ox] = biasA;
+                    for (int ox = 0; ox < 7; ++ox) acc[ox] = bias;
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky)
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int iy = oy - R + ky;
+                        if (iy < 0 || iy >= 7) continue;
 #pragma unroll
-                        for (int ip = 0; ip < 3; ++ip)
+                        for (int ip = 0; ip < NP; ++ip)
 #pragma unroll
                             for (int ox = 0; ox < 7; ++ox) {
-                                const int xpc = (ox >> 1) - 1 + ip;
+                                const int xpc = first_pair(ox) + ip;
                                 if (xpc < 0 || xpc > 3) continue;
-                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[(ro + ky) * 4 + xpc]),
-                                                                 *reinterpret_cast<const h2*>(&wpA[(ky * 2 + (ox & 1)) * 3 + ip]),
+                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
+                                                                 *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * NP + ip]),
                                                                  acc[ox], false);
                             }
+                    }
 #pragma unroll
                     for (int ox = 0; ox < 7; ++ox) {
                         const float y = silu_scaled(acc[ox]);
@@ -1604,11 +1553,84 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                         *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
                     }
                 }
+                pooled[c] = psum;
+            };
+            // taps of the next round are requested before the current round computes
+#pragma unroll
+            for (int i = 0; i < 3 * KS; ++i) rawB[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 512 + tid) * 4u);
+            biasB = gload<float>(W.bdw, (unsigned)(512 + tid) * 4u);
+            dw_round(tid, rawA, biasA);
+            const int cl = tid & 127, p4 = tid >> 7, rb = 2 * p4;
+#pragma unroll
+            for (int i = 0; i < 3 * KS; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 1024 + cl) * 4u);
+            biasA = gload<float>(W.bdw, (unsigned)(1024 + cl) * 4u);
+            dw_round(512 + tid, rawB, biasB);
+            // Squeeze FC weights (fp16, 36 x 8 bytes per thread): requested before the last quarter round, which is
+            // pure VALU/LDS work (earlier the two tap buffers leave no registers for them).
+            {
+                const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)
+#pragma unroll
+                for (int i = 0; i < 36; ++i) fw1[i] = gload<u2v>(W.wr_t, (unsigned)(((32 * i + crl) * 48 + 4 * j4) * 2));
             }
-            part[p4 * 128 + cl] = psum;
-            T7_BAR();
-            if (tid < 128) pooled[1024 + tid] = ((part[tid] + part[128 + tid]) + part[256 + tid]) + part[384 + tid];
-        }
+            {
+                // Channels 1024..1151 (a quarter round) are shared by FOUR threads each so that all 8 waves stay busy:
+                // thread (channel, p) computes output rows 2p and 2p+1 from input rows 2p-R .. 2p+1+R (zeros outside
+                // the image).  In place needs every read of a channel before any write: barrier in between.
+                constexpr int NR = 2 + 2 * R;
+                const int c = 1024 + cl;
+                uint32_t wpA[2 * KS * NP];
+                tap_pairs(rawA, wpA);
+                unsigned char* col = ED + 2 * c;
+                uint32_t P[NR * 4];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int iy = rb - R + r;
+                    const bool rok = iy >= 0 && iy < 7;
+                    const unsigned char* rowp = col + (rok ? iy : 0) * (7 * T7_ES);
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * T7_ES);
+                        uint32_t hi = 0;
+                        if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * T7_ES);
+                        P[r * 4 + pp] = rok ? (lo | (hi << 16)) : 0u;
+                    }
+                }
+                T7_BAR();
+                float psum = 0.f;
+#pragma unroll
+                for (int ro = 0; ro < 2; ++ro) {
+                    const int oy = rb + ro;
+                    if (oy < 7) {
+                        float acc[7];
+#pragma unroll
+                        for (int ox = 0; ox < 7; ++ox) acc[ox] = biasA;
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                            for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+                                for (int ox = 0; ox < 7; ++ox) {
+                                    const int xpc = first_pair(ox) + ip;
+                                    if (xpc < 0 || xpc > 3) continue;
+                                    acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[(ro + ky) * 4 + xpc]),
+                                                                     *reinterpret_cast<const h2*>(&wpA[(ky * 2 + (ox & 1)) * NP + ip]),
+                                                                     acc[ox], false);
+                                }
+#pragma unroll
+                        for (int ox = 0; ox < 7; ++ox) {
+                            const float y = silu_scaled(acc[ox]);
+                            psum += y;
+                            *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
+                        }
+                    }
+                }
+                part[p4 * 128 + cl] = psum;
+                T7_BAR();
+                if (tid < 128) pooled[1024 + tid] = ((part[tid] + part[128 + tid]) + part[256 + tid]) + part[384 + tid];
+            }
+        };
+        if (ks3) dw_phase(std::integral_constant<int, 3>{});
+        else dw_phase(std::integral_constant<int, 5>{});
         T7_BAR();
         T7_TICK();
         if (a.dbg_dw) {

@@ -369,15 +369,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 // taps of tail7_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
-                const int ring = (5 - B.d.k) / 2;   // a 3x3 kernel (b15) sits in the middle of a 5x5 of zeros
                 auto tap = [&](int c, int ky, int kx) -> _Float16 {
-                    const int y = ky - ring, x = kx - ring;
-                    if (kx >= 5 || y < 0 || x < 0 || y >= B.d.k || x >= B.d.k) return (_Float16)0.0f;
-                    return (_Float16)w[(size_t)c * kk + y * B.d.k + x];
+                    return kx < B.d.k ? (_Float16)w[(size_t)c * kk + ky * B.d.k + kx] : (_Float16)0.0f;
                 };
                 for (int c = 0; c < B.ce; ++c)
-                    for (int ky = 0; ky < 5; ++ky)
-                        for (int d = 0; d < 3; ++d) {
+                    for (int ky = 0; ky < B.d.k; ++ky)
+                        for (int d = 0; d < 3; ++d) {   // slot 3*ky + d holds taps (2d, 2d+1) of kernel row ky
                             _Float16 h[2] = {tap(c, ky, 2 * d), tap(c, ky, 2 * d + 1)};
                             uint32_t u;
                             memcpy(&u, h, 4);
@@ -544,7 +541,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             for (int j = 0; j < 4; ++j) {
                 const BlockW& B = bb->blk[12 + j];
                 tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr, B.se_br, B.t_we, B.se_be, B.t_wproj, B.project.b,
-                                   B.d.cout, 0};
+                                   B.d.cout, B.d.k};
             }
             TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
         }
@@ -760,7 +757,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
 // One pass over n <= max_batch resident patches: split into lanes, fork from / join to the caller's stream.
 static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
 {
-    if (bb->nlanes == 1 || prof || n < 2 * bb->nlanes)
+    // Profiling records HIP events on each lane's own stream, i.e. durations as they are with the lanes running
+    // concurrently (what rocprofv3 sees); MMC_PROFILE_SERIAL=1 profiles one lane at a time instead (isolated kernels).
+    static const bool serial_prof = [] { const char* e = getenv("MMC_PROFILE_SERIAL"); return e && e[0] == '1'; }();
+    if (bb->nlanes == 1 || (prof && serial_prof) || n < 2 * bb->nlanes)
         return (n <= bb->lane_cap) ? forward_lane(bb, bb->lanes[0], patches_dev, n, out_dev, st, prof)
                                    : [&]() {
                                          for (int off = 0; off < n; off += bb->lane_cap) {
@@ -779,7 +779,7 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         if (cur <= 0) break;
         mmc_backbone::Lane& L = bb->lanes[l];
         HIP_TRY(hipStreamWaitEvent(L.stream, bb->fork, 0));
-        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * FEAT, L.stream, nullptr);
+        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * FEAT, L.stream, prof);
         if (r) return r;
         HIP_TRY(hipEventRecord(L.done, L.stream));
         HIP_TRY(hipStreamWaitEvent(st, L.done, 0));

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-launch table on the GPU box: HIP-event ms, algorithmic GB/s and TFLOP/s of every launch of one
 256-patch pass (median of --passes).  Development aid; bench.py is the judged entry point."""
-import argparse, sys
+import argparse, os, sys
+os.environ.setdefault("MMC_PROFILE_SERIAL", "1")   # isolated kernels: one lane at a time
 from collections import defaultdict
 from pathlib import Path
 import numpy as np
