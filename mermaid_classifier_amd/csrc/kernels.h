@@ -74,6 +74,25 @@ struct TailArgs {
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 
+// Squeeze-excite + project conv of one patch per workgroup (proj_patch_kernel)
+struct ProjPatchArgs {
+    const _Float16* X;        // [B][HW][K] depthwise output
+    const float* pool_part;   // [B][nparts][K] depthwise pool partials
+    const _Float16* wr_t;     // [K][CSP] squeeze FC (fp16, channel-major)
+    const float* br;          // [CSP]
+    const _Float16* we_t;     // [CSP][K] excite FC (fp16)
+    const float* be;          // [K]
+    const _Float16* wfrag;    // [N/16 up][K/32 up][64][8] project weights, MFMA fragment order, zero padded
+    const float* bias;        // [16 * ceil(N/16)]
+    const _Float16* res;      // [B][HW][N] skip input or null
+    _Float16* Y;              // [B][HW][N]
+    float* dbg_gate;          // optional [B][K]
+    float* dbg_clk;           // optional [B][8]: shader cycles of prologue, GEMM
+    int B, HW, K, N, CSP, nparts;
+    float psc;                // 1 / (HW * log2 e)
+};
+int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st);
+
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 int launch_mbconv_d(const MbArgs& a, hipStream_t st);   // dot2 depthwise variant (pair-interleaved LDS tile)
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,

@@ -1351,6 +1351,7 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // a pointer that came out of memory, moved to SGPRs (wave-uniform by construction) and to the global address space
 template <typename T>
 static __device__ __forceinline__ const GLOBAL_AS T* sgpr_ptr(const void* p)
@@ -1828,6 +1829,281 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
     }
 }
 // ---------------------------------------------------------------------------------------------
+// proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
+// 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
+// project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
+//   * the squeeze-excite gate is computed in the prologue from the depthwise kernel's pool partials (two
+//     matrix-vector products on fp16 weights, fp32 accumulate) -- no second launch, no gate tensor in HBM;
+//   * the project weights (N x K, <= 147 KB) are fetched once per patch, parked in LDS in MFMA fragment order,
+//     and every wave streams its pixel fragments of the patch's depthwise output (the B operand, gated in
+//     registers with v_fma_mixlo/hi_f16) against them: swapped MFMA, two pixel fragments per weight-fragment read.
+// 512 threads; wave w owns the pixel-fragment pairs w, w+8, ...; K is walked in chunks of CK k-steps with the
+// next chunk's pixel fragments in flight.  Template: KS = k-steps of 32 (K zero-padded), NF = 16-channel output
+// fragments (N zero-padded), HW = pixels per patch, RES = skip connection.
+// ---------------------------------------------------------------------------------------------
+static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
+{
+    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
+    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
+    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
+    uint4 d;
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
+          "v"(g1[2]), "v"(g1[3]));
+    return d;
+}
+
+template <int KS, int NF, int HW, bool RES>
+__global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
+{
+    constexpr int CK = (KS <= 8) ? KS : (KS % 7 == 0 ? 7 : 5);   // k-steps per chunk (KS = 21 -> 7, 15 -> 5)
+    constexpr int NCH = KS / CK;
+    static_assert(KS % CK == 0, "chunking");
+    constexpr int NPF = (HW + 15) / 16, NPAIR = (NPF + 1) / 2;
+    constexpr int NWCH = NF * KS * 64;                 // 16-byte chunks of the weight image
+    constexpr int WPT = (NWCH + 511) / 512;            // chunks per thread
+    constexpr int KP = 32 * KS;
+    constexpr bool EARLY_RES = KS < 21;   // the 672-channel blocks (b9, b10) are at the register limit
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;                                           // [NF][KS][64 lanes][16 B]
+    float* pooled = reinterpret_cast<float*>(smem + NF * KS * 1024);    // [KP]
+    float* gate = pooled + KP;                                          // [KP]
+    float* part = reinterpret_cast<float*>(smem);                       // [64][32] FC1 partials: alias wl (written later)
+    float* rs = part + 64 * 32;                                         // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int K = a.K, CSP = a.CSP;
+    long long tk0 = 0, tk1 = 0, tk2 = 0;
+    if (a.dbg_clk) tk0 = (long long)__builtin_readcyclecounter();
+    const GLOBAL_AS _Float16* wfrag = sgpr_ptr<_Float16>(a.wfrag);
+    const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.wr_t);
+    const GLOBAL_AS _Float16* we_t = sgpr_ptr<_Float16>(a.we_t);
+    const GLOBAL_AS float* pp = sgpr_ptr<float>(a.pool_part);
+    // ---- the first chunk of this wave's first pixel-fragment pair is requested before anything else: its HBM/MALL
+    //      latency hides behind the whole prologue
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
+    auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = 32 * pr + 16 * i + m;
+            const int pix = p < HW ? p : HW - 1;
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                // Columns beyond K (zero-padded k-steps) re-read the row's last 8 channels: their gate and weights are
+                // zero, so no lane predicate is needed -- a per-lane branch around the load would make the compiler
+                // drain ALL outstanding loads (vmcnt(0)) at every chunk boundary and undo the prefetch.
+                const int k = 32 * (ch * CK + u) + 8 * q;
+                const u4v raw = gload<u4v>(xg, (unsigned)((pix * K + (k < K ? k : K - 8)) * 2));
+                const uint32_t keep = k < K ? 0xffffffffu : 0u;   // select, not a branch
+                const u4v msk = {raw.x & keep, raw.y & keep, raw.z & keep, raw.w & keep};
+                dst[i][u] = *reinterpret_cast<const h8*>(&msk);
+            }
+        }
+    };
+    h8 xc[2][CK], xn[2][CK];
+    if (wave < NPAIR) load_chunk(wave, 0, xc);
+    // ---- everything the prologue needs is requested up front, so it costs one memory round trip: the project
+    //      weights (registers now, parked in LDS after the squeeze-excite FCs), both FC weight sets, the pool partials
+    h8 wreg[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int c = tid + 512 * i;
+        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
+    }
+    // FC1: thread = 4 outputs (j4) x one of 64 channel slices (k = sl, sl + 64, ...)
+    constexpr int FC1_IT = (KP + 63) / 64;
+    const int G = CSP >> 2;
+    const int sl = tid / G, j4 = tid - sl * G;
+    const bool fc1_thr = sl < 64;
+    u2v w1[FC1_IT];
+#pragma unroll
+    for (int i = 0; i < FC1_IT; ++i) {
+        const int k = sl + 64 * i;
+        w1[i] = gload<u2v>(wr_t, (unsigned)(((fc1_thr && k < K ? k : 0) * CSP + 4 * j4) * 2));
+    }
+    // FC2: thread = channels 2*tid, 2*tid + 1 (one dword of We^T per squeeze unit)
+    const int k2 = 2 * tid;
+    const bool fc2_thr = k2 < K;
+    uint32_t w2[28];
+#pragma unroll
+    for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
+    const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
+    const float brv = tid < CSP ? a.br[tid] : 0.f;
+    // ---- squeeze: pooled[k] = sum over the depthwise kernel's tiles ----
+    for (int k = tid; k < KP; k += 512) {
+        float s = 0.f;
+        if (k < K)
+            for (int p = 0; p < a.nparts; ++p) s += gload<float>(pp, (unsigned)(((b * a.nparts + p) * K + k) * 4));
+        pooled[k] = s;
+    }
+    T7_BAR();
+    // ---- FC1: r = silu(br + psc * pooled . Wr^T) ----
+    if (fc1_thr) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < FC1_IT; ++i) {
+            const int k = sl + 64 * i;
+            const float x = k < K ? pooled[k] : 0.f;
+            acc[0] = fma_mix_lo(w1[i].x, x, acc[0]);
+            acc[1] = fma_mix_hi(w1[i].x, x, acc[1]);
+            acc[2] = fma_mix_lo(w1[i].y, x, acc[2]);
+            acc[3] = fma_mix_hi(w1[i].y, x, acc[3]);
+        }
+        *reinterpret_cast<f4*>(part + sl * 32 + 4 * j4) = acc;
+    }
+    T7_BAR();
+    if (tid < CSP) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int w = 0; w < 64; ++w) s += part[w * 32 + tid];
+        rs[tid] = silu_f(s * a.psc + brv);
+    }
+    T7_BAR();
+    // ---- FC2: gate = sigmoid(be + r . We^T) ----
+    {
+        float a0 = be0, a1 = be1;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float r = j < CSP ? rs[j] : 0.f;
+            a0 = fma_mix_lo(w2[j], r, a0);
+            a1 = fma_mix_hi(w2[j], r, a1);
+        }
+        if (k2 < KP) {   // zero beyond K: the zero-padded x columns stay zero
+            const float g0 = fc2_thr ? sigmoid_f(a0) : 0.f, g1 = fc2_thr ? sigmoid_f(a1) : 0.f;
+            gate[k2] = g0;
+            gate[k2 + 1] = g1;
+            if (a.dbg_gate && fc2_thr) {
+                a.dbg_gate[(size_t)b * K + k2] = g0;
+                a.dbg_gate[(size_t)b * K + k2 + 1] = g1;
+            }
+        }
+    }
+    T7_BAR();          // FC1 partials (aliasing wl) are dead from here
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int c = tid + 512 * i;
+        if (c < NWCH) *reinterpret_cast<h8*>(wl + c * 16) = wreg[i];
+    }
+    T7_BAR();
+    if (a.dbg_clk) tk1 = (long long)__builtin_readcyclecounter();
+    // ---- project: Y[pixel][n] = sum_k (X[pixel][k] * gate[k]) W[n][k] + bias (+ residual) ----
+    f4 bv[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) bv[nf] = *reinterpret_cast<const f4*>(a.bias + 16 * nf + 4 * q);
+#pragma unroll 1
+    for (int pr = wave; pr < NPAIR; pr += 8) {
+        f4 acc[2][NF];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[i][nf] = bv[nf];
+        // skip-connection input of this pair (unpredicated, clamped addresses: one round trip for all of it): requested
+        // before the k-loop where registers allow (EARLY_RES), else at the start of the epilogue
+        h4 rv[2][NF];
+        auto load_res = [&]() {
+            if (!RES) return;
+            const GLOBAL_AS _Float16* rg = sgpr_ptr<_Float16>(a.res) + (size_t)b * HW * a.N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = 32 * pr + 16 * i + m;
+                const int pc = p < HW ? p : HW - 1;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    const int c = 16 * nf + 4 * q;
+                    rv[i][nf] = gload<h4>(rg, (unsigned)((pc * a.N + (c < a.N ? c : 0)) * 2));
+                }
+            }
+        };
+        if (EARLY_RES) load_res();
+        h8 wcur[NF];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) wcur[nf] = *reinterpret_cast<const h8*>(wl + ((nf * KS) * 64 + lane) * 16);
+        f4 gc0 = *reinterpret_cast<const f4*>(gate + 8 * q), gc1 = *reinterpret_cast<const f4*>(gate + 8 * q + 4);
+        long long tka = 0;
+        if (a.dbg_clk) tka = (long long)__builtin_readcyclecounter();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            // the next chunk (of this pair, or the first one of the wave's next pair) is in flight while this one computes
+            // (always issued -- the wave's last pair re-reads its own first chunk -- so that the load count at the wait
+            // below is a compile-time constant; a conditional load makes the compiler wait for vmcnt(0))
+            if (ch + 1 < NCH) load_chunk(pr, ch + 1, xn);
+            else load_chunk(pr + 8 < NPAIR ? pr + 8 : pr, 0, xn);
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                const int ks = ch * CK + u;
+                // weight fragments (LDS) and gates of the NEXT k-step are read while this one's MFMAs run: otherwise
+                // every fragment's LDS latency sits in front of its two MFMAs
+                const int kn = ks + 1 < KS ? ks + 1 : 0;
+                h8 wnx[NF];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) wnx[nf] = *reinterpret_cast<const h8*>(wl + ((nf * KS + kn) * 64 + lane) * 16);
+                const f4 gn0 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q);
+                const f4 gn1 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q + 4);
+                __builtin_amdgcn_sched_barrier(0);   // keep those reads AHEAD of this k-step's MFMAs (the scheduler sinks them otherwise)
+                h8 xb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 o = gate_h8(*reinterpret_cast<const uint4*>(&xc[i][u]), gc0, gc1);
+                    xb[i] = *reinterpret_cast<const h8*>(&o);
+                }
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[nf], xb[0], acc[0][nf], 0, 0, 0);
+                    acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[nf], xb[1], acc[1][nf], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) wcur[nf] = wnx[nf];
+                gc0 = gn0;
+                gc1 = gn1;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < CK; ++u) xc[i][u] = xn[i][u];
+        }
+        if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 2] = (float)((long long)__builtin_readcyclecounter() - tka);
+        if (!EARLY_RES) load_res();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = 32 * pr + 16 * i + m;
+            if (p >= HW) continue;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int c = 16 * nf + 4 * q;
+                if (c >= a.N) continue;   // N is a multiple of 4 (padding fragments are dropped)
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[i][nf][j];
+                if (RES) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)rv[i][nf][j];
+                }
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+                *reinterpret_cast<h4*>(a.Y + ((size_t)b * HW + p) * a.N + c) = o;
+            }
+        }
+    }
+    if (a.dbg_clk) {
+        T7_BAR();
+        tk2 = (long long)__builtin_readcyclecounter();
+        if (tid == 0) { a.dbg_clk[(size_t)b * 8] = (float)(tk1 - tk0); a.dbg_clk[(size_t)b * 8 + 1] = (float)(tk2 - tk1); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused stem + block-0 depthwise: u8 patch -> [stem conv3x3s2 + bias + SiLU] -> LDS -> [depthwise 3x3 s1 +
 // bias + SiLU] -> fp16 NHWC (112x112x32) + squeeze-excite partial sums.  The 112x112x32 stem output (the
 // largest tensor of the net after the expanded ones) never goes to HBM.  Same two-phase structure as
@@ -2292,4 +2568,37 @@ int launch_tail7(const TailArgs& a, hipStream_t st)
     hipLaunchKernelGGL(tail7_kernel, dim3(a.B), dim3(512), T7_LDS, st, a);
     LAUNCH_CHECK();
     return 0;
+}
+
+template <int KS, int NF, int HW, bool RES>
+static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
+{
+    const int lds = NF * KS * 1024 + 2 * 32 * KS * 4;
+    if (NF * KS * 1024 < (64 * 32 + 32) * 4) return -10;   // FC1 scratch aliases the weight image
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_patch_kernel<KS, NF, HW, RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((proj_patch_kernel<KS, NF, HW, RES>), dim3(a.B), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
+{
+    if (a.B < 1 || a.CSP < 4 || a.CSP > 32 || (a.CSP & 3) || a.nparts < 1) return -11;
+    const int ks = (a.K + 31) / 32, nf = (a.N + 15) / 16;
+#define PP_CASE(KS_, NF_, HW_, RES_) \
+    if (ks == KS_ && nf == NF_ && a.HW == HW_ && (a.res != nullptr) == RES_) return launch_proj_patch_t<KS_, NF_, HW_, RES_>(a, st);
+    PP_CASE(5, 3, 784, false)    // b3: 144 -> 40 @ 28x28
+    PP_CASE(8, 3, 784, true)     // b4: 240 -> 40
+    PP_CASE(8, 5, 196, false)    // b5: 240 -> 80 @ 14x14
+    PP_CASE(15, 5, 196, true)    // b6, b7: 480 -> 80
+    PP_CASE(15, 7, 196, false)   // b8: 480 -> 112
+    PP_CASE(21, 7, 196, true)    // b9, b10: 672 -> 112
+#undef PP_CASE
+    return -5;
 }

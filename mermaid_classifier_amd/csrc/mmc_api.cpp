@@ -119,6 +119,12 @@ struct BlockW {
     _Float16* t_wproj = nullptr;
     uint32_t* t_dwp = nullptr;
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
+    // proj_patch_kernel packing (blocks 3..10): project weights/bias padded to whole fragments, SE FCs as above with
+    // Cs padded to a multiple of 4
+    bool pp = false;
+    _Float16* pp_w = nullptr;
+    float *pp_b = nullptr, *pp_br = nullptr;
+    int pp_csp = 0;
 };
 
 // Output tile (TH x TWo) and channel chunk CC of the fused kernel, per B0 block (index 1..15):
@@ -161,6 +167,7 @@ struct mmc_backbone {
     size_t ws_bytes = 0;
     std::vector<void*> allocs;
     bool keep = false, fuse_stem = false;
+    float* dbg_clk = nullptr;        // keep mode: per-patch phase cycle counts of the patch-resident kernels
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     std::map<std::string, Saved> saved;
     int last_n = 0;
@@ -291,6 +298,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->max_batch = max_batch;
     const char* keep = getenv("MMC_KEEP_ACTIVATIONS");
     bb->keep = keep && keep[0] == '1';
+    if (bb->keep) { int r__ = dev_alloc(bb, &bb->dbg_clk, (size_t)max_batch * 8); if (r__) { mmc_backbone_destroy(bb); return r__; } }
     std::vector<uint64_t> table(2 * (size_t)nt);
     memcpy(table.data(), base + 16, (size_t)nt * 16);
     BlobReader rd{base, nbytes, nt, table.data()};
@@ -330,6 +338,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
     bb->fuse_stem = fuse_enabled;
+    const char* pp_env = getenv("MMC_PROJSE");
+    const bool projse_enabled = fuse_enabled && !(pp_env && pp_env[0] == '0');
     const char* tail_env = getenv("MMC_TAIL");
     const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
     int H = IMG / 2;
@@ -407,15 +417,22 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
-            if (tail_enabled && i >= 12 && i <= 15 && B.cs == 48) {
-                std::vector<_Float16> wrt((size_t)B.ce * 48), wet((size_t)48 * B.ce);
+            const bool pp_blk = projse_enabled && i >= 3 && i <= 10;
+            if ((tail_enabled && i >= 12 && i <= 15 && B.cs == 48) || pp_blk) {
+                // fp16, transposed for matrix-vector use: Wr^T [ce][csp], We^T [csp][ce] (csp = Cs padded to 4)
+                const int csp = (B.cs + 3) / 4 * 4;
+                std::vector<_Float16> wrt((size_t)B.ce * csp, (_Float16)0.0f), wet((size_t)csp * B.ce, (_Float16)0.0f);
                 for (int c = 0; c < B.ce; ++c)
-                    for (int j = 0; j < 48; ++j) {
-                        wrt[(size_t)c * 48 + j] = (_Float16)wr[(size_t)j * B.ce + c];
+                    for (int j = 0; j < B.cs; ++j) {
+                        wrt[(size_t)c * csp + j] = (_Float16)wr[(size_t)j * B.ce + c];
                         wet[(size_t)j * B.ce + c] = (_Float16)we[(size_t)c * B.cs + j];
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_wr, wrt));
                 TRY_OR_FREE(dev_upload(bb, &B.t_we, wet));
+                std::vector<float> brp(csp > 32 ? csp : 32, 0.f);
+                for (int j = 0; j < B.cs; ++j) brp[j] = br[j];
+                TRY_OR_FREE(dev_upload(bb, &B.pp_br, brp));
+                B.pp_csp = csp;
             }
             TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
             TRY_OR_FREE(dev_upload(bb, &B.se_wep, wep));
@@ -429,6 +446,20 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
             TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
+            if (projse_enabled && i >= 3 && i <= 10) {
+                // proj_patch_kernel: fragment order as below, K and N zero-padded to whole fragments
+                const int ks32 = (B.ce + 31) / 32, nf = (B.d.cout + 15) / 16;
+                std::vector<_Float16> wf((size_t)nf * ks32 * 512, (_Float16)0.0f);
+                for (int c = 0; c < B.d.cout; ++c)
+                    for (int k = 0; k < B.ce; ++k)
+                        wf[((((size_t)(c / 16) * ks32 + k / 32) * 64) + ((k % 32) / 8) * 16 + (c % 16)) * 8 + (k % 8)] =
+                            (_Float16)(float)(w[(size_t)c * B.ce + k] * (1.0 / LOG2E));
+                TRY_OR_FREE(dev_upload(bb, &B.pp_w, wf));
+                std::vector<float> bp((size_t)16 * nf, 0.f);
+                for (int c = 0; c < B.d.cout; ++c) bp[c] = b[c];
+                TRY_OR_FREE(dev_upload(bb, &B.pp_b, bp));
+                B.pp = true;
+            }
             if (tail_enabled && i >= 12 && i <= 15) {
                 // plain MFMA fragment order [cout/16][ce/32][64 lanes][8]: lane (q*16 + m) holds W[16nf + m][32ks + 8q ..+8]
                 const int ks32 = B.ce / 32;
@@ -737,6 +768,31 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         }
         snprintf(nm, sizeof nm, "b%d.dw", i);
         if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
+        if (B.pp && B.fused && B.t_wr) {
+            // squeeze-excite + project, one patch per workgroup (proj_patch_kernel): no gate tensor, one launch
+            ProjPatchArgs pa{};
+            pa.X = ws.dwbuf; pa.pool_part = ws.pool_part; pa.wr_t = B.t_wr; pa.br = B.pp_br; pa.we_t = B.t_we; pa.be = B.se_be;
+            pa.wfrag = B.pp_w; pa.bias = B.pp_b; pa.res = B.skip ? x : nullptr; pa.Y = y;
+            pa.dbg_gate = bb->keep ? ws.gate : nullptr;
+            pa.dbg_clk = bb->keep ? bb->dbg_clk : nullptr;
+            pa.B = n; pa.HW = HWo; pa.K = B.ce; pa.N = B.d.cout; pa.CSP = B.pp_csp; pa.nparts = nparts;
+            pa.psc = (float)(1.0 / ((double)HWo * LOG2E));
+            snprintf(nm, sizeof nm, "b%d.projse", i);
+            char pl[48];
+            snprintf(pl, sizeof pl, "proj_patch<%d,%d,%d,%d>", (B.ce + 31) / 32, (B.d.cout + 15) / 16, HWo, B.skip ? 1 : 0);
+            STEP(nm, pl, launch_proj_patch(pa, st));
+            if (bb->keep) {
+                int r;
+                snprintf(nm, sizeof nm, "b%d.gate", i);
+                if ((r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st))) return r;
+                snprintf(nm, sizeof nm, "b%d.out", i);
+                if ((r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st))) return r;
+                snprintf(nm, sizeof nm, "b%d.clk", i);
+                if ((r = save_act(bb, nm, bb->dbg_clk, (size_t)n * 8, false, st))) return r;
+            }
+            _Float16* t = x; x = y; y = t;
+            continue;
+        }
         snprintf(nm, sizeof nm, "b%d.gate", i);
         STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wrp, B.se_br, B.se_wep, B.se_be,
                                             ws.gate, st));

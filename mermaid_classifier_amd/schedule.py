@@ -43,6 +43,9 @@ def b0_launches(batch: int) -> List[Launch]:
         res = m_out * cout * 2 if (s == 1 and cin == cout) else 0
         out.append(Launch(f"b{i}.project", "project", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2,
                           2 * m_out * ce * cout))
+        if 3 <= i <= 10:   # squeeze-excite + project in one launch (proj_patch_kernel): no gate tensor in HBM
+            out.append(Launch(f"b{i}.projse", "projse", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2 + 2 * cs * ce * 2,
+                              2 * m_out * ce * cout + 2 * batch * 2 * cs * ce))
         h = ho
     # blocks 12..15 chained in one launch (tail7_kernel): only the 7x7 block input/output and the weights move
     tail = [l for l in out if l.name.split(".")[0] in ("b12", "b13", "b14", "b15") and l.kind in ("mbconv", "se", "project")]
@@ -60,7 +63,7 @@ def totals(batch: int, launched=None) -> Dict[str, float]:
         names = set(launched)
         ls = [l for l in ls if l.name in names]
     else:
-        ls = [l for l in ls if l.kind not in ("mbconv", "stem_dw", "tail")]
+        ls = [l for l in ls if l.kind not in ("mbconv", "stem_dw", "tail", "projse")]
     return {"bytes": float(sum(l.bytes for l in ls)), "flops": float(sum(l.flops for l in ls)),
             "bytes_per_patch": sum(l.bytes for l in ls) / batch, "flops_per_patch": sum(l.flops for l in ls) / batch}
 

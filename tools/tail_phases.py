@@ -26,6 +26,14 @@ def main():
         clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :6]
         med = np.median(clk, axis=0)
         print(f"b{blk}: " + "  ".join(f"{nm} {c:8.0f}" for nm, c in zip(names, med)) + f"   total {med.sum():8.0f} cycles")
+    projse(bb, n)
+
+def projse(bb, n):
+    for blk in range(3, 11):
+        clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :3]
+        med = np.median(clk, axis=0)
+        print(f"b{blk}.projse: prologue {med[0]:8.0f}  gemm {med[1]:8.0f} cycles (wave 0, last pair: k-loop {med[2]:8.0f})")
+
 
 if __name__ == "__main__":
     main()
