@@ -64,13 +64,28 @@ struct TailBlock {
     int ks;                 // depthwise kernel size: 5 or 3
 };
 struct TailArgs {
-    const _Float16* X;      // [B][49][192]
-    _Float16* Y;            // [B][49][cout of the last block]
-    int B, nblk;
+    const _Float16* X;      // [B][49][192] block input (or [B][49][320] when in_wide); unused with pre_D
+    _Float16* Y;            // [B][49][cout of the last block]; unused with head_w
+    int B, nblk;            // nblk blocks from the table (0..4)
     const TailBlock* blk;   // device table, nblk consecutive rows
     _Float16* dbg_dw;       // optional [B][49][1152]: depthwise output of the last block run (nblk == 1)
-    float* dbg_gate;        // optional [B][1152]
+    float* dbg_gate;        // optional [B][1152] (or [B][672] for the pre-block)
     float* dbg_clk;         // optional [B][8]: shader cycles per phase (expand, dw, fc1, fc2, gate, project)
+    // optional pre-block: second half of block 11 (squeeze-excite + project 672 -> 192, no skip) on its depthwise output
+    const _Float16* pre_D;      // [B][49][672] or null
+    const float* pre_pool;      // [B][672] pool sums (one tile per patch)
+    const _Float16* pre_wr_t;   // [672][28]
+    const float* pre_br;        // [28+]
+    const _Float16* pre_we_t;   // [28][672]
+    const float* pre_be;        // [672]
+    const _Float16* pre_wproj;  // [12][24][64][8] (k-steps 21..23 zero)
+    const float* pre_bproj;     // [192]
+    // optional head: conv 320 -> 1280 + swish + average pool -> feat
+    const _Float16* head_w;     // [80][10][64][8] or null
+    const float* head_b;        // [1280]
+    float* feat;                // [B][1280]
+    float inv_hw;               // 1 / (49 log2 e)
+    int in_wide;                // input X is [B][49][320] (head-only launches)
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 

@@ -1367,6 +1367,27 @@ static __device__ __forceinline__ T gload(const GLOBAL_AS void* base, unsigned b
 {
     return *reinterpret_cast<const GLOBAL_AS T*>(reinterpret_cast<const GLOBAL_AS char*>(base) + byte_off);
 }
+static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
+{
+    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
+    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
+    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
+    uint4 d;
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
+          "v"(g1[2]), "v"(g1[3]));
+    return d;
+}
+
 // Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), NOT for its outstanding global loads:
 // __syncthreads() also drains vmcnt, which would serialise every weight prefetch issued across a phase boundary.
 // No global data is exchanged between the threads of this kernel, so the LDS-only form is sufficient.
@@ -1383,16 +1404,205 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
     float* rs = reinterpret_cast<float*>(smem + T7_OFF_RS);
     const int tid0 = threadIdx.x;
     const int b = blockIdx.x;
-    {
+    // ---- project conv pieces shared by the block loop and the b11 pre-block --------------------------------------
+    // Output fragments (16 channels) nf0 .. nf0+nfn-1 of this wave; weight image [cout/16][KS][64 lanes][16 B].
+    auto proj_prefetch = [&](const GLOBAL_AS _Float16* wproj, const GLOBAL_AS float* bproj, int KS, int nf0, int nfn, int lane, int q,
+                             f4 (&pbias)[3], unsigned (&wo)[3], h8 (&wa)[3][4]) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int nf = nf0 + (i < nfn ? i : 0);   // surplus slots alias fragment nf0 (loaded, never used)
+            pbias[i] = gload<f4>(bproj, (unsigned)(16 * nf + 4 * q) * 4u);
+            wo[i] = (unsigned)((nf * KS * 64 + lane) * 16);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) wa[i][d] = gload<h8>(wproj, wo[i] + (unsigned)(d * 1024));
+        }
+    };
+    // mode 0: X <- fp16(acc + X) in place (192 outputs, skip); 1: ED <- fp16(acc) as [49][320] (b15); 2: X <- fp16(acc).
+    // KS (k-steps, a multiple of 4) pixel fragments come from ED one k-step ahead of their MFMAs, weight fragments four
+    // k-steps ahead.  The K order is part of the result: same for every workgroup.
+    auto proj_run = [&](const GLOBAL_AS _Float16* wproj, int KS, int mode, int nf0, int nfn, int lane, int m, int q,
+                        const int (&pixc)[4], f4 (&pbias)[3], unsigned (&wo)[3], h8 (&wa)[3][4]) {
+        f4 acc[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) acc[i][pf] = pbias[i];
+        const unsigned char* bxp[4];
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * T7_ES + 16 * q;
+        // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside one
+        auto k_loop = [&](auto nf_tag) {
+            constexpr int NF = decltype(nf_tag)::value;
+            h8 bx[4], bn[4];
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf]);
+#pragma unroll 1
+            for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int ks = ks0 + d;
+                    const int kn = ks + 1 < KS ? ks + 1 : KS - 1;   // last step re-reads itself (unused)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+                    h8 w[NF];
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) w[i] = wa[i][d];
+                    const int kw = ks + 4 < KS ? ks + 4 : KS - 1;   // the last four prefetches re-read the last step (unused)
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) wa[i][d] = gload<h8>(wproj, wo[i] + (unsigned)(kw * 1024));
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+#pragma unroll
+                        for (int pf = 0; pf < 4; ++pf)
+                            acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], bx[pf], acc[i][pf], 0, 0, 0);
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+                }
+            }
+        };
+        if (nfn == 3) k_loop(std::integral_constant<int, 3>{});
+        else if (nfn == 2) k_loop(std::integral_constant<int, 2>{});
+        else k_loop(std::integral_constant<int, 1>{});
+        if (mode == 1) {   // b15: the result replaces ED (all reads of ED are done after the barrier)
+            T7_BAR();
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+                if (16 * pf + m >= T7_PIX) continue;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (i >= nfn) continue;
+                    h4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[i][pf][j];
+                    *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_YS + (16 * (nf0 + i) + 4 * q) * 2) = o;
+                }
+            }
+        } else {           // 192 outputs into X (each lane owns its elements: in place is safe)
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf) {
+                if (16 * pf + m >= T7_PIX) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i >= nfn) continue;
+                    h4* px = reinterpret_cast<h4*>(XL + (16 * pf + m) * T7_XS + (16 * (nf0 + i) + 4 * q) * 2);
+                    h4 r = {0, 0, 0, 0};
+                    if (mode == 0) r = *px;
+                    h4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[i][pf][j] + (float)r[j]);
+                    *px = o;
+                }
+            }
+        }
+    };
+    if (a.pre_D) {
+        // ---- block 11, second half (its depthwise output D11[49][672] and pool sums come from mbconv_a_kernel):
+        //      squeeze-excite, gate, project 672 -> 192 (no skip) -> X.  Same recipes as in the block loop below. ----
+        const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int m = lane & 15, q = lane >> 4;
+        const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.pre_wr_t);
+        const GLOBAL_AS _Float16* we_t = sgpr_ptr<_Float16>(a.pre_we_t);
+        const GLOBAL_AS _Float16* wproj = sgpr_ptr<_Float16>(a.pre_wproj);
+        const GLOBAL_AS float* bproj = sgpr_ptr<float>(a.pre_bproj);
+        // FC weights first (registers): thread = (4 squeeze outputs j4, one of 48 channel slices) / channels 2t, 2t+1
+        const int sl = tid / 7, j4 = tid - sl * 7;
+        const bool fc_thr = tid < 336;
+        u2v w1[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) w1[i] = gload<u2v>(wr_t, (unsigned)((((fc_thr ? sl : 0) + 48 * i) * 28 + 4 * j4) * 2));
+        uint32_t w2[28];
+#pragma unroll
+        for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)((j * 672 + (fc_thr ? 2 * tid : 0)) * 2));
+        const float be0 = fc_thr ? a.pre_be[2 * tid] : 0.f, be1 = fc_thr ? a.pre_be[2 * tid + 1] : 0.f;
+        const float brv = tid < 28 ? a.pre_br[tid] : 0.f;
+        {
+            const _Float16* dg = a.pre_D + (size_t)b * T7_PIX * 672;
+            for (int e = tid; e < T7_PIX * 96; e += 512) {   // 84 real 16-byte columns + 12 of zeros (k-steps 21..23)
+                const int pix = e / 96, oc = e - pix * 96;
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (oc < 84) v = *reinterpret_cast<const h8*>(dg + pix * 672 + oc * 8);
+                *reinterpret_cast<h8*>(ED + pix * T7_ES + oc * 16) = v;
+            }
+            for (int kk = tid; kk < 672; kk += 512) pooled[kk] = a.pre_pool[(size_t)b * 672 + kk];
+        }
+        T7_BAR();
+        if (fc_thr) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 14; ++i) {
+                const float x = pooled[sl + 48 * i];
+                acc[0] = fma_mix_lo(w1[i].x, x, acc[0]);
+                acc[1] = fma_mix_hi(w1[i].x, x, acc[1]);
+                acc[2] = fma_mix_lo(w1[i].y, x, acc[2]);
+                acc[3] = fma_mix_hi(w1[i].y, x, acc[3]);
+            }
+            *reinterpret_cast<f4*>(part + sl * 32 + 4 * j4) = acc;
+        }
+        T7_BAR();
+        if (tid < 28) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int w = 0; w < 48; ++w) s += part[w * 32 + tid];
+            rs[tid] = silu_f(s * (float)(1.0 / (49.0 * 1.4426950408889634)) + brv);
+        }
+        T7_BAR();
+        {
+            float a0 = be0, a1 = be1;
+#pragma unroll
+            for (int j = 0; j < 28; ++j) {
+                const float r = rs[j];
+                a0 = fma_mix_lo(w2[j], r, a0);
+                a1 = fma_mix_hi(w2[j], r, a1);
+            }
+            if (fc_thr) {
+                const float g0 = sigmoid_f(a0), g1 = sigmoid_f(a1);
+                gate[2 * tid] = g0;
+                gate[2 * tid + 1] = g1;
+                if (a.dbg_gate) {
+                    a.dbg_gate[(size_t)b * 672 + 2 * tid] = g0;
+                    a.dbg_gate[(size_t)b * 672 + 2 * tid + 1] = g1;
+                }
+            }
+        }
+        const bool lowh = wave < 4;
+        const int nfn = lowh ? 2 : 1, nf0 = lowh ? 2 * wave : wave + 4;
+        int pixc[4];
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) pixc[pf] = (16 * pf + m) < T7_PIX ? (16 * pf + m) : (T7_PIX - 1);
+        f4 pbias[3];
+        unsigned wo[3];
+        h8 wa[3][4];
+        proj_prefetch(wproj, bproj, 24, nf0, nfn, lane, q, pbias, wo, wa);
+        T7_BAR();
+        for (int e = tid; e < T7_PIX * 84; e += 512) {
+            const int pix = e / 84, oc = e - pix * 84;
+            uint4* pv = reinterpret_cast<uint4*>(ED + pix * T7_ES + oc * 16);
+            const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
+            const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
+            *pv = gate_h8(*pv, g0, g1);
+        }
+        T7_BAR();
+        proj_run(wproj, 24, 2, nf0, nfn, lane, m, q, pixc, pbias, wo, wa);
+        T7_BAR();
+    } else if (a.in_wide) {
+        // head-only use (per-tensor tests): the input is block 15's output [49][320]
+        const int tid = tid0;
+        const _Float16* xg = a.X + (size_t)b * T7_PIX * 320;
+        for (int e = tid; e < T7_PIX * 40; e += 512) {
+            const int pix = e / 40, p16 = e - pix * 40;
+            *reinterpret_cast<h8*>(ED + pix * T7_YS + p16 * 16) = *reinterpret_cast<const h8*>(xg + pix * 320 + p16 * 8);
+        }
+        __syncthreads();
+    } else {
         const int tid = tid0;
         const _Float16* xg = a.X + (size_t)b * T7_PIX * T7_C;
         for (int e = tid; e < T7_PIX * 24; e += 512) {
             const int pix = e / 24, p16 = e - pix * 24;
             *reinterpret_cast<h8*>(XL + pix * T7_XS + p16 * 16) = *reinterpret_cast<const h8*>(xg + pix * T7_C + p16 * 8);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    bool out_wide = false;
+    bool out_wide = a.in_wide != 0;
 #pragma unroll 1
     for (int nb = 0; nb < a.nblk; ++nb) {
         // One table row via scalar loads.  Pointers that come out of memory are "flat" to the compiler; the casts
@@ -1699,14 +1909,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         f4 pbias[3];
         unsigned wo[3];
         h8 wa[3][4];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int nf = nf0 + (i < nfn ? i : 0);   // surplus slots alias fragment nf0 (loaded, never used)
-            pbias[i] = gload<f4>(W.bproj, (unsigned)(16 * nf + 4 * q) * 4u);
-            wo[i] = (unsigned)((nf * 36 * 64 + lane) * 16);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) wa[i][d] = gload<h8>(W.wproj, wo[i] + (unsigned)(d * 1024));
-        }
+        proj_prefetch(W.wproj, W.bproj, 36, nf0, nfn, lane, q, pbias, wo, wa);
         T7_BAR();
         T7_TICK();
         if (a.dbg_gate) {
@@ -1715,95 +1918,15 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // ---------------- gate, in place ----------------
         for (int e = tid; e < T7_PIX * 144; e += 512) {
             const int pix = e / 144, oc = e - pix * 144;
-            h8* pv = reinterpret_cast<h8*>(ED + pix * T7_ES + oc * 16);
-            h8 v = *pv;
+            uint4* pv = reinterpret_cast<uint4*>(ED + pix * T7_ES + oc * 16);
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
             const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = (_Float16)((float)v[j] * g0[j]);
-                v[4 + j] = (_Float16)((float)v[4 + j] * g1[j]);
-            }
-            *pv = v;
+            *pv = gate_h8(*pv, g0, g1);   // fp32 product, one rounding, one VALU op per element
         }
         T7_BAR();
         T7_TICK();
         // ---------------- project + bias (+ residual) ----------------
-        {
-            f4 acc[3][4];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf) acc[i][pf] = pbias[i];
-            const unsigned char* bxp[4];
-#pragma unroll
-            for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * T7_ES + 16 * q;
-            // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside
-            // one.  Pixel fragments are read one k-step ahead of the MFMAs that use them, weight fragments four
-            // k-steps ahead.  The K order is part of the result: same for every workgroup.
-            auto k_loop = [&](auto nf_tag) {
-                constexpr int NF = decltype(nf_tag)::value;
-                h8 bx[4], bn[4];
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf]);
-#pragma unroll 1
-                for (int ks0 = 0; ks0 < 36; ks0 += 4) {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int ks = ks0 + d;
-                        const int kn = ks + 1 < 36 ? ks + 1 : 35;   // last step re-reads itself (unused)
-#pragma unroll
-                        for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
-                        h8 w[NF];
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) w[i] = wa[i][d];
-                        const int kw = ks + 4 < 36 ? ks + 4 : 35;   // the last four prefetches re-read step 35 (unused)
-#pragma unroll
-                        for (int i = 0; i < NF; ++i) wa[i][d] = gload<h8>(W.wproj, wo[i] + (unsigned)(kw * 1024));
-#pragma unroll
-                        for (int i = 0; i < NF; ++i)
-#pragma unroll
-                            for (int pf = 0; pf < 4; ++pf)
-                                acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], bx[pf], acc[i][pf], 0, 0, 0);
-#pragma unroll
-                        for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
-                    }
-                }
-            };
-            if (nfn == 3) k_loop(std::integral_constant<int, 3>{});
-            else if (nfn == 2) k_loop(std::integral_constant<int, 2>{});
-            else k_loop(std::integral_constant<int, 1>{});
-            if (!wide) {   // 192 outputs, skip connection: X <- fp16(acc + X), in place (each lane owns its elements)
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf) {
-                    if (16 * pf + m >= T7_PIX) continue;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if (i >= nfn) continue;
-                        h4* px = reinterpret_cast<h4*>(XL + (16 * pf + m) * T7_XS + (16 * (nf0 + i) + 4 * q) * 2);
-                        const h4 r = *px;
-                        h4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)(acc[i][pf][j] + (float)r[j]);
-                        *px = o;
-                    }
-                }
-            } else {       // b15: 320 outputs, no skip; the result replaces ED (all reads of ED are done after the barrier)
-                T7_BAR();
-#pragma unroll
-                for (int pf = 0; pf < 4; ++pf) {
-                    if (16 * pf + m >= T7_PIX) continue;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (i >= nfn) continue;
-                        h4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[i][pf][j];
-                        *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_YS + (16 * (nf0 + i) + 4 * q) * 2) = o;
-                    }
-                }
-            }
-        }
+        proj_run(W.wproj, 36, wide ? 1 : 0, nf0, nfn, lane, m, q, pixc, pbias, wo, wa);
         out_wide = wide;
         T7_BAR();
         T7_TICK();
@@ -1812,7 +1935,67 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int i = 0; i < 6; ++i) a.dbg_clk[(size_t)b * 8 + i] = (float)(tk[i + 1] - tk[i]);
         }
     }
-    if (!out_wide) {
+    if (a.head_w) {
+        // ---- head: features[n] = mean over pixels of silu(b[n] + Y15[pixel] . Wh[n]) (1280 x 320), Y15 in ED [49][320].
+        //      Wave w owns output fragments 10w .. 10w+9 in two groups of five (accumulators 5 x 4 pixel fragments);
+        //      pixel fragments come from LDS per k-step, weight fragments stream from L2 one k-step ahead. ----
+        const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int m = lane & 15, q = lane >> 4;
+        const GLOBAL_AS _Float16* hw = sgpr_ptr<_Float16>(a.head_w);
+        const GLOBAL_AS float* hb = sgpr_ptr<float>(a.head_b);
+        const unsigned char* bxp[4];
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + ((16 * pf + m) < T7_PIX ? (16 * pf + m) : (T7_PIX - 1)) * T7_YS + 16 * q;
+#pragma unroll 1
+        for (int g = 0; g < 2; ++g) {
+            const int nfb = 10 * wave + 5 * g;
+            f4 acc[5][4];
+            h8 wc[5], wn[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const f4 bv = gload<f4>(hb, (unsigned)(16 * (nfb + i) + 4 * q) * 4u);
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) acc[i][pf] = bv;
+                wc[i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10) * 64 + lane) * 16));
+            }
+#pragma unroll 2
+            for (int ks = 0; ks < 10; ++ks) {
+                const int kn = ks + 1 < 10 ? ks + 1 : 9;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wn[i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10 + kn) * 64 + lane) * 16));
+                h8 bx[4];
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * ks);
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], bx[pf], acc[i][pf], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) wc[i] = wn[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                f4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) {
+                    const bool ok = 16 * pf + m < T7_PIX;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum[j] += ok ? silu_scaled(acc[i][pf][j]) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = sum[j];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    sum[j] = v * a.inv_hw;
+                }
+                if (m == 0) *reinterpret_cast<f4*>(a.feat + (size_t)b * 1280 + 16 * (nfb + i) + 4 * q) = sum;
+            }
+        }
+    } else if (!out_wide) {
         const int tid = tid0;
         _Float16* yg = a.Y + (size_t)b * T7_PIX * T7_C;
         for (int e = tid; e < T7_PIX * 24; e += 512) {
@@ -1828,6 +2011,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         }
     }
 }
+
 // ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
@@ -1841,27 +2025,6 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 // next chunk's pixel fragments in flight.  Template: KS = k-steps of 32 (K zero-padded), NF = 16-channel output
 // fragments (N zero-padded), HW = pixels per patch, RES = skip connection.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
-{
-    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
-    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
-    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
-    uint4 d;
-    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 1"
-        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
-        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
-          "v"(g1[2]), "v"(g1[3]));
-    return d;
-}
-
 template <int KS, int NF, int HW, bool RES>
 __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 {
@@ -2557,7 +2720,8 @@ int launch_mbconv_d(const MbArgs& a, hipStream_t st)
 
 int launch_tail7(const TailArgs& a, hipStream_t st)
 {
-    if (a.nblk < 1 || a.nblk > 4 || a.B < 1) return -9;
+    if (a.nblk < 0 || a.nblk > 4 || a.B < 1) return -9;
+    if (a.nblk == 0 && !a.pre_D && !a.head_w) return -9;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel),

@@ -168,6 +168,9 @@ struct mmc_backbone {
     std::vector<void*> allocs;
     bool keep = false, fuse_stem = false;
     float* dbg_clk = nullptr;        // keep mode: per-patch phase cycle counts of the patch-resident kernels
+    // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
+    bool tail_full = false;
+    _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     std::map<std::string, Saved> saved;
     int last_n = 0;
@@ -417,7 +420,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
-            const bool pp_blk = projse_enabled && i >= 3 && i <= 10;
+            const bool pp_blk = (projse_enabled && i >= 3 && i <= 10) || (tail_enabled && i == 11);
             if ((tail_enabled && i >= 12 && i <= 15 && B.cs == 48) || pp_blk) {
                 // fp16, transposed for matrix-vector use: Wr^T [ce][csp], We^T [csp][ce] (csp = Cs padded to 4)
                 const int csp = (B.cs + 3) / 4 * 4;
@@ -459,6 +462,15 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 for (int c = 0; c < B.d.cout; ++c) bp[c] = b[c];
                 TRY_OR_FREE(dev_upload(bb, &B.pp_b, bp));
                 B.pp = true;
+            }
+            if (tail_enabled && i == 11 && B.ce == 672 && B.d.cout == 192) {
+                // tail7 pre-block: fragment order [12][24][64][8], k-steps 21..23 zero (its k-loop runs 4 steps at a time)
+                std::vector<_Float16> wf((size_t)12 * 24 * 512, (_Float16)0.0f);
+                for (int c = 0; c < B.d.cout; ++c)
+                    for (int k = 0; k < B.ce; ++k)
+                        wf[((((size_t)(c / 16) * 24 + k / 32) * 64) + ((k % 32) / 8) * 16 + (c % 16)) * 8 + (k % 8)] =
+                            (_Float16)(float)(w[(size_t)c * B.ce + k] * (1.0 / LOG2E));
+                TRY_OR_FREE(dev_upload(bb, &bb->pre_wproj, wf));
             }
             if (tail_enabled && i >= 12 && i <= 15) {
                 // plain MFMA fragment order [cout/16][ce/32][64 lanes][8]: lane (q*16 + m) holds W[16nf + m][32ks + 8q ..+8]
@@ -560,6 +572,14 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
         TAKE(b, FEAT, "head.bias");
         TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
+        if (tail_enabled) {   // the same weights in plain fragment order [80][10][64][8] for tail7's head phase
+            std::vector<_Float16> wf((size_t)FEAT * HEAD_IN);
+            for (int c = 0; c < FEAT; ++c)
+                for (int k = 0; k < HEAD_IN; ++k)
+                    wf[((((size_t)(c / 16) * (HEAD_IN / 32) + k / 32) * 64) + ((k % 32) / 8) * 16 + (c % 16)) * 8 + (k % 8)] =
+                        (_Float16)(float)(w[(size_t)c * HEAD_IN + k] * LOG2E);
+            TRY_OR_FREE(dev_upload(bb, &bb->head_wfrag, wf));
+        }
     }
     if (tail_enabled) {
         bool ok = true;
@@ -575,6 +595,10 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                                    B.d.cout, B.d.k};
             }
             TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
+            const char* tf = getenv("MMC_TAIL_FULL");
+            const BlockW& B11 = bb->blk[11];
+            bb->tail_full = !(tf && tf[0] == '0') && bb->pre_wproj && bb->head_wfrag && B11.t_wr && B11.pp_csp == 28 && B11.fused &&
+                            B11.f_tiles_x * B11.f_tiles_y == 1;
         }
     }
     if (rd.next != nt) {
@@ -695,16 +719,20 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
         if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     }
+    bool tail_done = false;
     for (int i = 0; i < 16; ++i) {
         if (i == 12 && bb->tail_tab) {
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
             if (!bb->keep) {
-                TailArgs ta{x, y, n, 4, bb->tail_tab, nullptr, nullptr, nullptr};
+                TailArgs ta{};
+                ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 4; ta.blk = bb->tail_tab;
                 STEP("b12-15.tail", "tail7", launch_tail7(ta, st));
                 _Float16* t = x; x = y; y = t;
             } else {
                 for (int j = 0; j < 4; ++j) {   // block at a time so every intermediate tensor can be read back
-                    TailArgs ta{x, y, n, 1, bb->tail_tab + j, ws.dwbuf, ws.gate, ws.pool_part};
+                    TailArgs ta{};
+                    ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 1; ta.blk = bb->tail_tab + j;
+                    ta.dbg_dw = ws.dwbuf; ta.dbg_gate = ws.gate; ta.dbg_clk = ws.pool_part;
                     snprintf(nm, sizeof nm, "b%d.tail", 12 + j);
                     STEP(nm, "tail7", launch_tail7(ta, st));
                     int r;
@@ -768,6 +796,29 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         }
         snprintf(nm, sizeof nm, "b%d.dw", i);
         if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
+        if (i == 11 && bb->tail_full) {
+            // block 11's squeeze-excite + project, blocks 12..15 and the head conv in ONE launch (tail7_kernel): from
+            // the last 14x14 depthwise output straight to the feature vector.  Per-tensor mode runs it in pieces.
+            const BlockW& B11 = B;
+            TailArgs ta{};
+            ta.B = n; ta.blk = bb->tail_tab;
+            ta.pre_D = ws.dwbuf; ta.pre_pool = ws.pool_part; ta.pre_wr_t = B11.t_wr; ta.pre_br = B11.pp_br; ta.pre_we_t = B11.t_we;
+            ta.pre_be = B11.se_be; ta.pre_wproj = bb->pre_wproj; ta.pre_bproj = B11.project.b;
+            ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
+            if (!bb->keep) {
+                ta.nblk = 4; ta.head_w = bb->head_wfrag; ta.head_b = bb->head.b; ta.feat = out_dev;
+                STEP("b11-head.tail", "tail7", launch_tail7(ta, st));
+                tail_done = true;
+                break;
+            }
+            int r;
+            ta.nblk = 0; ta.Y = y; ta.dbg_gate = ws.gate;
+            STEP("b11.tail", "tail7", launch_tail7(ta, st));
+            if ((r = save_act(bb, "b11.gate", ws.gate, (size_t)n * B.ce, false, st))) return r;
+            if ((r = save_act(bb, "b11.out", y, (size_t)n * 49 * 192, true, st))) return r;
+            _Float16* t = x; x = y; y = t;
+            continue;
+        }
         if (B.pp && B.fused && B.t_wr) {
             // squeeze-excite + project, one patch per workgroup (proj_patch_kernel): no gate tensor, one launch
             ProjPatchArgs pa{};
@@ -804,7 +855,15 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         _Float16* t = x; x = y; y = t;
     }
     const int HWh = bb->blk[15].Ho * bb->blk[15].Ho;
-    STEP("head", gemm_label(bb->head, n * HWh, EPI_GAP, false, false), run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
+    if (tail_done) {
+        // features already written by tail7_kernel
+    } else if (bb->tail_full) {   // per-tensor mode: the head phase of tail7_kernel on its own
+        TailArgs ta{};
+        ta.X = x; ta.B = n; ta.nblk = 0; ta.blk = bb->tail_tab; ta.in_wide = 1;
+        ta.head_w = bb->head_wfrag; ta.head_b = bb->head.b; ta.feat = out_dev; ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
+        STEP("head.tail", "tail7", launch_tail7(ta, st));
+    } else
+        STEP("head", gemm_label(bb->head, n * HWh, EPI_GAP, false, false), run_gemm(bb->head, x, n * HWh, nullptr, EPI_GAP, nullptr, HWh, nullptr, out_dev, st));
     bb->last_n = n;
 #undef STEP
     return 0;

@@ -51,6 +51,13 @@ def b0_launches(batch: int) -> List[Launch]:
     tail = [l for l in out if l.name.split(".")[0] in ("b12", "b13", "b14", "b15") and l.kind in ("mbconv", "se", "project")]
     w_bytes = 4 * (1152 * 192 * 2 + 15 * 1152 * 4 + 2 * 48 * 1152 * 2) + (3 * 192 + 320) * 1152 * 2
     out.append(Launch("b12-15.tail", "tail", batch * 49 * (192 + 320) * 2 + w_bytes, sum(l.flops for l in tail)))
+    # ... and with block 11's squeeze-excite + project in front and the head conv behind: one launch from the last
+    # 14x14 depthwise output to the feature vector
+    b11 = [l for l in out if l.name in ("b11.gate", "b11.project")]
+    head_flops = 2 * batch * 49 * 320 * FEATURE_DIM
+    out.append(Launch("b11-head.tail", "tail", batch * (49 * 672 * 2 + 672 * 4 + FEATURE_DIM * 4) + w_bytes
+                      + 192 * 672 * 2 + 2 * 28 * 672 * 2 + FEATURE_DIM * 320 * 2,
+                      sum(l.flops for l in tail) + sum(l.flops for l in b11) + head_flops))
     out.append(Launch("head", "head", batch * h * h * 320 * 2 + batch * FEATURE_DIM * 4 + FEATURE_DIM * 320 * 2,
                       2 * batch * h * h * 320 * FEATURE_DIM))
     return out
