@@ -678,6 +678,53 @@ __global__ __launch_bounds__(1024) void se_fused_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// se_small_kernel: squeeze-excite for the early blocks (C <= 256 channels, Cs <= 16 squeeze units), one patch per
+// 256-thread workgroup.  The work is tiny (b0: 32x8, b1: 96x4, b2: 144x6 MACs per FC), what matters is that the
+// launch gets onto the chip at once while the other lane's big kernels fill it: a 16-wave / 52 KB workgroup of
+// se_fused_kernel has to wait for a whole compute unit to drain, a 4-wave / 1 KB one fits anywhere.
+// fp32 throughout, natural weight layouts, fixed summation order (slab sums in 4 chains, wave butterfly for FC1).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_small_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
+                                                       const float* __restrict__ wr,   // [Cs][C], carries 1/(HW log2e)
+                                                       const float* __restrict__ br,   // [Cs]
+                                                       const float* __restrict__ we,   // [C][Cs]
+                                                       const float* __restrict__ be,   // [C]
+                                                       float* __restrict__ gate)       // [B][C]
+{
+    __shared__ float pooled[256];
+    __shared__ float rs[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (tid < C) {
+        const float* pp = pool_part + (size_t)b * nparts * C + tid;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = 0;
+        for (; p + 3 < nparts; p += 4) {
+            s0 += pp[(size_t)p * C];
+            s1 += pp[(size_t)(p + 1) * C];
+            s2 += pp[(size_t)(p + 2) * C];
+            s3 += pp[(size_t)(p + 3) * C];
+        }
+        for (; p < nparts; ++p) s0 += pp[(size_t)p * C];
+        pooled[tid] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = __builtin_fmaf(pooled[c], wr[(size_t)j * C + c], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) rs[j] = silu_f(s + br[j]);
+    }
+    __syncthreads();
+    if (tid < C) {
+        float acc = be[tid];
+        for (int j = 0; j < Cs; ++j) acc = __builtin_fmaf(rs[j], we[(size_t)tid * Cs + j], acc);
+        gate[(size_t)b * C + tid] = sigmoid_f(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Calibrated MLP head, fp32 end to end (the reference gate is max|dp| <= 1e-6, inference/export.py:31).
 // Y[m][n] = act( sum_k X[m][k] W[n][k] + b[n] ) on the exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
 // Lane (i=l&15, q=l>>4) loads 4 consecutive k of its row (16 B) and feeds element s at step s, so
@@ -2571,6 +2618,15 @@ int launch_dwconv(const DwArgs& a, hipStream_t st)
     DW_CASE(5, 2, 7)
 #undef DW_CASE
     return -4;
+}
+
+int launch_se_small(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
+                    const float* we, const float* be, float* gate, hipStream_t st)
+{
+    if (C > 256 || Cs > 16 || B < 1) return -12;
+    hipLaunchKernelGGL(se_small_kernel, dim3(B), dim3(256), 0, st, pool_part, nparts, C, Cs, wr, br, we, be, gate);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* WrP, const float* br,

@@ -104,6 +104,7 @@ struct BlockW {
     float *dw_w = nullptr, *dw_b = nullptr;                    // [k*k][ce], [ce]
     float *se_br = nullptr, *se_be = nullptr;
     float *se_wrp = nullptr, *se_wep = nullptr;   // fragment-ordered fp32 squeeze-excite weights
+    float *se_wr_nat = nullptr, *se_we_nat = nullptr, *se_br_nat = nullptr;   // natural fp32 copies for se_small_kernel (C <= 256)
     // depthwise launch geometry
     int tw = 0, CG = 0, S = 0, iters = 0, parts = 0;
     // fused expand+depthwise (mbconv_a_kernel) geometry; fused == false -> separate GEMM + dwconv
@@ -437,6 +438,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 TRY_OR_FREE(dev_upload(bb, &B.pp_br, brp));
                 B.pp_csp = csp;
             }
+            if (B.ce <= 256 && B.cs <= 16) {   // early blocks: light per-patch squeeze-excite kernel
+                std::vector<float> wrn((size_t)B.cs * B.ce);
+                for (size_t e = 0; e < wrn.size(); ++e) wrn[e] = (float)(wr[e] * psc);
+                TRY_OR_FREE(dev_upload(bb, &B.se_wr_nat, wrn));
+                TRY_OR_FREE(dev_upload(bb, &B.se_we_nat, std::vector<float>(we, we + (size_t)B.ce * B.cs)));
+                TRY_OR_FREE(dev_upload(bb, &B.se_br_nat, std::vector<float>(br, br + B.cs)));
+            }
             TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
             TRY_OR_FREE(dev_upload(bb, &B.se_wep, wep));
             std::vector<float> brs(48, 0.f);
@@ -720,6 +728,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     }
     bool tail_done = false;
+    static const bool se_small_enabled = [] { const char* e = getenv("MMC_SE_SMALL"); return !(e && e[0] == '0'); }();
     for (int i = 0; i < 16; ++i) {
         if (i == 12 && bb->tail_tab) {
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
@@ -845,6 +854,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             continue;
         }
         snprintf(nm, sizeof nm, "b%d.gate", i);
+        if (B.se_wr_nat && se_small_enabled)
+            STEP(nm, "se_small", launch_se_small(ws.pool_part, nparts, n, B.ce, B.cs, B.se_wr_nat, B.se_br_nat, B.se_we_nat, B.se_be,
+                                                 ws.gate, st));
+        else
         STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wrp, B.se_br, B.se_wep, B.se_be,
                                             ws.gate, st));
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
