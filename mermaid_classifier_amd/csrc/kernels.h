@@ -109,6 +109,8 @@ struct ProjPatchArgs {
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st);
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
+// block 1 reading block 0's depthwise output, with block 0's SE scale + project conv folded in
+int launch_mbconv_pre(const MbArgs& a, const _Float16* pre_w, const float* pre_b, const float* pre_gate, hipStream_t st);
 int launch_mbconv_d(const MbArgs& a, hipStream_t st);   // dot2 depthwise variant (pair-interleaved LDS tile)
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
                 hipStream_t st);

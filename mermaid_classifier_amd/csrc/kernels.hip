@@ -884,6 +884,27 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
     return d;
 }
 
+static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
+{
+    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
+    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
+    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
+    uint4 d;
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
+          "v"(g1[2]), "v"(g1[3]));
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused MBConv front half: expand 1x1 (+bias+SiLU) -> LDS -> depthwise KSxKS stride ST (+bias+SiLU)
 // -> fp16 NHWC to HBM, plus squeeze-excite partial sums.  The 6x-expanded tensor never leaves the CU.
@@ -905,7 +926,11 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
 // weight fragments are streamed once per PB patches and all four waves have MFMA fragments to work on.
 // WLDS: the chunk's expand weights (fragment order, Wfrag) are copied to LDS in one burst at kernel start and
 // read back lane-linearly per MFMA; otherwise fragments stream from L2 (Wexp rows), one fragment ahead.
-template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB, bool WLDS>
+// PRE (block 1 only): the kernel's input is block 0's DEPTHWISE output [B][H][W][32]; block 0's squeeze-excite scale and
+// project conv (32 -> 16, one MFMA per 16 positions) run on the freshly loaded fragments, so block 0's output tensor and
+// its project launch do not exist.  The project result lands as 4 consecutive channels per lane (4q..4q+3); the expand
+// weights are packed with the matching K permutation (slot 8q+j <- channel 4q+j, j < 4) so no lane exchange is needed.
+template <int KS, int ST, int TW, int KSTEPS, int NPAIR, int CC, int TWO, int PB, bool WLDS, bool PRE = false>
 __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restrict__ X,     // [B][H][W][Cin]
                                                        const _Float16* __restrict__ Wexp,  // [Ce][32*KSTEPS] natural rows
                                                        const float* __restrict__ bexp,     // [Ce]
@@ -915,9 +940,13 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                                                        float* __restrict__ pool_part,      // [B][ntiles][Ce]
                                                        int H, int W, int Cin, int Ce, int Ho, int Wo, int pad, int TH,
                                                        int tiles_x, int wl_off, int red_off, int nB,
-                                                       const _Float16* __restrict__ Wfrag, int wfr_off)
+                                                       const _Float16* __restrict__ Wfrag, int wfr_off,
+                                                       const _Float16* __restrict__ pre_w = nullptr,   // [64][8] project fragment
+                                                       const float* __restrict__ pre_b = nullptr,      // [16]
+                                                       const float* __restrict__ pre_gate = nullptr)   // [B][32]
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(!PRE || (KSTEPS == 1 && PB == 1), "PRE: one k-step, one patch per workgroup");
     constexpr int Kp = 32 * KSTEPS;
     constexpr int TWo = TWO, CCG = CC / 8, S = 256 / CCG;
     constexpr int ES = CC * 2 + 16;  // bytes per E row
@@ -966,6 +995,23 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                 xf[pr][i][ks] = v;
             }
         }
+    if (PRE) {
+        const h8 wpre = *reinterpret_cast<const h8*>(pre_w + lane * 8);
+        const f4 bpre = *reinterpret_cast<const f4*>(pre_b + 4 * q);
+        const f4 g0 = *reinterpret_cast<const f4*>(pre_gate + (size_t)b * 32 + 8 * q);
+        const f4 g1 = *reinterpret_cast<const f4*>(pre_gate + (size_t)b * 32 + 8 * q + 4);
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint4 gx = gate_h8(*reinterpret_cast<const uint4*>(&xf[pr][i][0]), g0, g1);
+                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&gx), bpre, 0, 0, 0);
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (_Float16)acc[j];   // block 0's output, rounded to fp16 as the separate path stores it
+                xf[pr][i][0] = v;
+            }
+    }
     if (WLDS) {
         const uint4* src = reinterpret_cast<const uint4*>(Wfrag + (size_t)chunk * NTC * KSTEPS * 512);
         uint4* dst = reinterpret_cast<uint4*>(smem + wfr_off);
@@ -1414,27 +1460,6 @@ static __device__ __forceinline__ T gload(const GLOBAL_AS void* base, unsigned b
 {
     return *reinterpret_cast<const GLOBAL_AS T*>(reinterpret_cast<const GLOBAL_AS char*>(base) + byte_off);
 }
-static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
-{
-    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
-    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
-    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
-    uint4 d;
-    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 1"
-        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
-        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
-          "v"(g1[2]), "v"(g1[3]));
-    return d;
-}
-
 // Workgroup barrier that only waits for this wave's LDS traffic (lgkmcnt), NOT for its outstanding global loads:
 // __syncthreads() also drains vmcnt, which would serialise every weight prefetch issued across a phase boundary.
 // No global data is exchanged between the threads of this kernel, so the LDS-only form is sufficient.
@@ -2706,6 +2731,20 @@ static int launch_mbconv_t(const MbArgs& a, hipStream_t st)
                            st, a.X, a.Wexp, a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo,
                            a.pad, a.TH, a.tiles_x, a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off);
     }
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mbconv_pre(const MbArgs& a, const _Float16* pre_w, const float* pre_b, const float* pre_gate, hipStream_t st)
+{
+    // block 1 with block 0's squeeze-excite scale + project conv folded in (mbconv_a_kernel, PRE)
+    if (!(a.ks == 3 && a.stride == 2 && a.tw == 2 && a.ksteps == 1 && a.npair == 3 && a.CC == 48 && a.TWo == 8 && a.pb == 1 &&
+          a.Cin == 32 && !a.wlds))
+        return -13;
+    dim3 grid(a.tiles_x * a.tiles_y, a.Ce / a.CC, a.B);
+    hipLaunchKernelGGL((mbconv_a_kernel<3, 2, 2, 1, 3, 48, 8, 1, false, true>), grid, dim3(256), a.lds_bytes, st, a.X, a.Wexp,
+                       a.bexp, a.Wdw, a.bdw, a.out, a.pool_part, a.H, a.W, a.Cin, a.Ce, a.Ho, a.Wo, a.pad, a.TH, a.tiles_x,
+                       a.wl_off, a.red_off, a.B, a.Wfrag, a.wfr_off, pre_w, pre_b, pre_gate);
     LAUNCH_CHECK();
     return 0;
 }

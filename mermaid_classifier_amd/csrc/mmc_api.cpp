@@ -170,6 +170,9 @@ struct mmc_backbone {
     bool keep = false, fuse_stem = false;
     float* dbg_clk = nullptr;        // keep mode: per-patch phase cycle counts of the patch-resident kernels
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
+    // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
+    bool fuse_b0b1 = false;
+    _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
     bool tail_full = false;
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
@@ -457,6 +460,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
             TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
+            if (i == 0 && fuse_enabled && B.ce == 32 && B.d.cout == 16) {
+                // block 0's project conv as ONE MFMA fragment (16 outputs x 32 inputs) for mbconv_a_kernel PRE
+                std::vector<_Float16> wf(512, (_Float16)0.0f);
+                for (int c = 0; c < 16; ++c)
+                    for (int k = 0; k < 32; ++k) wf[((k / 8) * 16 + c) * 8 + (k % 8)] = (_Float16)(float)(w[(size_t)c * 32 + k] * (1.0 / LOG2E));
+                TRY_OR_FREE(dev_upload(bb, &bb->b0_pre_w, wf));
+            }
             if (projse_enabled && i >= 3 && i <= 10) {
                 // proj_patch_kernel: fragment order as below, K and N zero-padded to whole fragments
                 const int ks32 = (B.ce + 31) / 32, nf = (B.d.cout + 15) / 16;
@@ -533,6 +543,15 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     for (int c = 0; c < B.ce; ++c)
                         for (int k = 0; k < B.d.cin; ++k) wn[(size_t)c * kp + k] = (_Float16)(float)(exp_w_host[(size_t)c * B.d.cin + k] * LOG2E);
                     TRY_OR_FREE(dev_upload(bb, &B.exp_nat, wn));
+                    if (i == 1 && B.d.cin == 16 && kp == 32) {
+                        // K-permuted copy for mbconv_a_kernel PRE: MFMA slot 8q+j holds input channel 4q+j (j < 4), the
+                        // rest zero -- the layout block 0's in-kernel project leaves in the lanes
+                        std::vector<_Float16> wq((size_t)B.ce * 32, (_Float16)0.0f);
+                        for (int c = 0; c < B.ce; ++c)
+                            for (int qq = 0; qq < 4; ++qq)
+                                for (int j = 0; j < 4; ++j) wq[(size_t)c * 32 + 8 * qq + j] = wn[(size_t)c * kp + 4 * qq + j];
+                        TRY_OR_FREE(dev_upload(bb, &bb->b1_exp_pre, wq));
+                    }
                     {   // fragment order: ((c/16 * ksteps + k/32) * 64 + (k%32)/8 * 16 + c%16) * 8 + k%8
                         std::vector<_Float16> wf((size_t)B.ce * kp, (_Float16)0.0f);
                         for (int c = 0; c < B.ce; ++c)
@@ -608,6 +627,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             bb->tail_full = !(tf && tf[0] == '0') && bb->pre_wproj && bb->head_wfrag && B11.t_wr && B11.pp_csp == 28 && B11.fused &&
                             B11.f_tiles_x * B11.f_tiles_y == 1;
         }
+    }
+    {
+        const char* e = getenv("MMC_FUSE_B0");
+        const BlockW& B1 = bb->blk[1];
+        bb->fuse_b0b1 = !(e && e[0] == '0') && bb->fuse_stem && bb->b0_pre_w && bb->b1_exp_pre && B1.fused && !B1.use_d && B1.f_TH == 8 &&
+                        B1.f_TWo == 8 && B1.f_CC == 48 && B1.f_tw == 2 && B1.f_pb == 1 && !B1.f_wlds && B1.f_npair == 3;
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -763,8 +788,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
         if (i == 0 && stem_fused) {
+            // with block 0's project folded into block 1's kernel the depthwise output goes to the spare activation
+            // buffer (block 1 reads it while writing its own depthwise output to dwbuf)
             STEP("stem+b0.dw", "stem_dw", launch_stem_dw(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, B.dw_w, B.dw_b,
-                                                          ws.dwbuf, ws.pool_part, n, st));
+                                                          bb->fuse_b0b1 ? y : ws.dwbuf, ws.pool_part, n, st));
             nparts = 49;
         } else if (B.fused) {
             MbArgs a{};
@@ -783,6 +810,11 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                 STEP(nm, fl, launch_mbconv_d(a, st));
             } else {
                 snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb, a.wlds);
+                if (i == 1 && bb->fuse_b0b1) {
+                    a.X = y; a.Cin = 32; a.Wexp = bb->b1_exp_pre;   // block 0's depthwise output; its gate is in ws.gate
+                    snprintf(nm, sizeof nm, "b0.project+b1.mbconv");
+                    STEP(nm, "mbconv_a_pre", launch_mbconv_pre(a, bb->b0_pre_w, bb->blk[0].project.b, ws.gate, st));
+                } else
                 STEP(nm, fl, launch_mbconv_a(a, st));
             }
         } else {
@@ -804,7 +836,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             STEP(nm, dl, launch_dwconv(d, st));
         }
         snprintf(nm, sizeof nm, "b%d.dw", i);
-        if (bb->keep) { int r = save_act(bb, nm, ws.dwbuf, (size_t)n * HWo * B.ce, true, st); if (r) return r; }
+        if (bb->keep) {
+            int r = save_act(bb, nm, (i == 0 && bb->fuse_b0b1 && stem_fused) ? y : ws.dwbuf, (size_t)n * HWo * B.ce, true, st);
+            if (r) return r;
+        }
         if (i == 11 && bb->tail_full) {
             // block 11's squeeze-excite + project, blocks 12..15 and the head conv in ONE launch (tail7_kernel): from
             // the last 14x14 depthwise output straight to the feature vector.  Per-tensor mode runs it in pieces.
@@ -861,6 +896,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         STEP(nm, "se_fused", launch_se_gate(ws.pool_part, nparts, n, B.ce, B.cs4, B.se_wrp, B.se_br, B.se_wep, B.se_be,
                                             ws.gate, st));
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
+        if (i == 0 && bb->fuse_b0b1 && stem_fused) continue;   // block 0's project runs inside block 1's kernel
         snprintf(nm, sizeof nm, "b%d.project", i);
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
         snprintf(nm, sizeof nm, "b%d.out", i);

@@ -39,8 +39,8 @@ def test_every_intermediate_matches_oracle(kept_backbone, oracle_net, kind):
     report = []
     worst = 0.0
     for name, t in taps.items():
-        if name == "features" or (kept_backbone.mode == "fused" and (name.endswith(".expand") or name == "stem")):
-            continue   # fused schedule: these tensors live only in LDS
+        if name == "features" or (kept_backbone.mode == "fused" and (name.endswith(".expand") or name in ("stem", "b0.out"))):
+            continue   # fused schedule: these tensors live only in LDS / registers
         o = t.numpy()
         if o.ndim == 4 and name.endswith(".gate"):
             o = o.reshape(o.shape[0], o.shape[1])
@@ -52,7 +52,7 @@ def test_every_intermediate_matches_oracle(kept_backbone, oracle_net, kind):
         report.append(f"{name:12s} rel_rms={err:.2e} maxabs={mx:.3e}")
         worst = max(worst, err)
     print("\n".join(report))
-    assert len(report) == (48 if kept_backbone.mode == "fused" else 64)
+    assert len(report) == (47 if kept_backbone.mode == "fused" else 64)
     depth_tol = 2e-2 if kind == "noise" else 1e-2
     assert worst < depth_tol, "\n".join(report)
     rel = np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)
