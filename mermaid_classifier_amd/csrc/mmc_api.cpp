@@ -172,6 +172,7 @@ struct mmc_backbone {
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
     bool fuse_b0b1 = false;
+    bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
     bool tail_full = false;
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
@@ -305,6 +306,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->max_batch = max_batch;
     const char* keep = getenv("MMC_KEEP_ACTIVATIONS");
     bb->keep = keep && keep[0] == '1';
+    { const char* e = getenv("MMC_SE_SMALL"); bb->se_small = !(e && e[0] == '0'); }
     if (bb->keep) { int r__ = dev_alloc(bb, &bb->dbg_clk, (size_t)max_batch * 8); if (r__) { mmc_backbone_destroy(bb); return r__; } }
     std::vector<uint64_t> table(2 * (size_t)nt);
     memcpy(table.data(), base + 16, (size_t)nt * 16);
@@ -753,7 +755,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
     }
     bool tail_done = false;
-    static const bool se_small_enabled = [] { const char* e = getenv("MMC_SE_SMALL"); return !(e && e[0] == '0'); }();
+    const bool se_small_enabled = bb->se_small;
     for (int i = 0; i < 16; ++i) {
         if (i == 12 && bb->tail_tab) {
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)

@@ -200,3 +200,27 @@ def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone
     g = bb.extract(q)
     assert np.array_equal(g[:256], f) and np.array_equal(g[256:], f[:44])
     bb.close()
+
+
+@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_LANES"])
+def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_backbone, knob, monkeypatch):
+    """Each fusion has an environment switch (the separate kernels stay in the library as the reference
+    schedule).  With any one of them off -- or a single lane -- the features must still pass the golden gates, and
+    the default schedule must agree with the variant to within fp16 rounding of the intermediates."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    p = ref.natural_patches(8, seed=7)
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
+    base = bb.extract(p)
+    bb.close()
+    monkeypatch.setenv(knob, "1" if knob == "MMC_LANES" else "0")
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
+    try:
+        got = bb.extract(p)
+    finally:
+        bb.close()
+    want = golden_backbone["natural8"]
+    assert rel_l2(got, want).max() < TOL_NATURAL and cosine(got, want).min() >= COS_GATE
+    assert rel_l2(got, base).max() < TOL_NATURAL
+    if knob == "MMC_LANES":
+        assert np.array_equal(got, base)          # lanes only split the batch: bitwise identical
