@@ -129,3 +129,49 @@ def test_driver_on_gpu_matches_direct_extraction(tmp_path, synth_sd):
                 np.testing.assert_array_equal(got.get_array((r, cc)), row.astype(np.float32))
     finally:
         bb.close()
+
+
+@pytest.mark.gpu
+def test_config3_chain_driver_to_npy_to_labels(tmp_path, synth_sd, oracle_net):
+    """BASELINE config 3 end to end, in miniature: images x 25 points (the 5x5 grid geometry of the reference's
+    docs/pyspacer/0032dba6_points.csv, scaled) -> driver (GPU crop, cross-image batches) -> .featurevector files ->
+    extract_reference_features stacking (file order, then point order) -> (N, 1280) .npy -> calibrated head.
+    Checked against the oracle chain: per-image crop + fp32 forward, stacked the same way, reference-restated head."""
+    import torch
+    from conftest import GOLDEN, cosine, rel_l2
+    from mermaid_classifier_amd import load_predictor
+    from mermaid_classifier_amd.backbone import Backbone
+    from mermaid_classifier_amd.extract_reference_features import main as stack_main
+    from mermaid_classifier_amd.inference import params_from_torchscript
+    from mermaid_classifier_amd.pipeline import BatchedExtractor
+    from oracle import head_ref, pyspacer_ref
+    rng = np.random.default_rng(3)
+    H, W = 609, 696                                        # 4872 x 5568 / 8
+    grid = [(int(H * (2 * i + 1) / 10), int(W * (2 * j + 1) / 10)) for i in range(5) for j in range(5)]
+    imgs = {}
+    from scipy.ndimage import zoom
+    for i in range(3):                                     # smooth (image-like) content: bilinearly upsampled noise
+        base = rng.integers(0, 255, (H // 16 + 2, W // 16 + 2, 3)).astype(np.float32)
+        imgs[f"{i:04d}"] = np.clip(zoom(base, (16, 16, 1), order=1)[:H, :W], 0, 255).astype(np.uint8)
+    pts = {k: list(grid) for k in imgs}
+    bb = Backbone(synth_sd, device=0, max_batch=32)
+    try:
+        c = driver.process_source(source_id="3", images=pts, load_image=imgs.__getitem__, store_features=driver.fs_store(str(tmp_path), "3"),
+                                  extractor=BatchedExtractor(bb, batch_patches=32))
+    finally:
+        bb.close()
+    assert (c.images_ok, c.images_failed) == (3, 0)
+    files = [str(tmp_path / driver.feature_key("3", k)) for k in sorted(imgs)]
+    out = tmp_path / "reference_features.npy"
+    stack_main(["--out", str(out)] + files)
+    got = np.load(out)
+    assert got.shape == (75, 1280) and got.dtype == np.float32
+    want = pyspacer_ref.stack_reference_features([pyspacer_ref.extract(oracle_net, imgs[k], pts[k]) for k in sorted(imgs)])
+    assert cosine(got, want).min() >= 0.999 and rel_l2(got, want).max() < 1e-2
+    pred = load_predictor(GOLDEN / "head108" / "model.pt", GOLDEN / "head108" / "model.json")
+    prm = params_from_torchscript(torch.jit.load(str(GOLDEN / "head108" / "model.pt")))
+    p_ref = head_ref.predict_proba(want, prm.weights, prm.biases, prm.a, prm.b, 1280)
+    p_got = pred.predict_proba(got)
+    top2 = np.sort(p_ref, 1)[:, -2:]
+    decided = (top2[:, 1] - top2[:, 0]) > 1e-3
+    assert decided.sum() > 40 and np.array_equal(p_got.argmax(1)[decided], p_ref.argmax(1)[decided])
