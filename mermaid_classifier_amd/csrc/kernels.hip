@@ -2124,36 +2124,31 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.wr_t);
     const GLOBAL_AS _Float16* we_t = sgpr_ptr<_Float16>(a.we_t);
     const GLOBAL_AS float* pp = sgpr_ptr<float>(a.pool_part);
-    // ---- the first chunk of this wave's first pixel-fragment pair is requested before anything else: its HBM/MALL
-    //      latency hides behind the whole prologue
-    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
-    auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
+    // ---- The prologue is a dependent chain (pool sums -> FC1 -> FC2 -> gate) beside ~300 KB of bulk loads (project
+    //      weights, first pixel fragments).  Loads return in order and a wave cannot pass a barrier before it has
+    //      ISSUED its loads (the memory pipe takes 64 B/clk), so: chain inputs first (pool partials, then the FC
+    //      weights), all unpredicated and straight-line; the bulk loads go out after the first barrier and stream
+    //      in while the FCs compute.
+    float ps0 = 0.f, ps1 = 0.f;
+    {
+        const int k0 = tid < K ? tid : 0, k1 = tid + 512 < K ? tid + 512 : 0;
+        if (a.nparts == 1) {
+            ps0 = gload<float>(pp, (unsigned)((b * K + k0) * 4));
+            ps1 = gload<float>(pp, (unsigned)((b * K + k1) * 4));
+        } else {   // up to 16 tiles per patch (b3: 14, b4: 4, b5: 7): every load issued before the first add
+            float v0[16], v1[16];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int p = 32 * pr + 16 * i + m;
-            const int pix = p < HW ? p : HW - 1;
+            for (int p = 0; p < 16; ++p) {
+                const int pc = p < a.nparts ? p : 0;
+                v0[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k0) * 4));
+                v1[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k1) * 4));
+            }
 #pragma unroll
-            for (int u = 0; u < CK; ++u) {
-                // Columns beyond K (zero-padded k-steps) re-read the row's last 8 channels: their gate and weights are
-                // zero, so no lane predicate is needed -- a per-lane branch around the load would make the compiler
-                // drain ALL outstanding loads (vmcnt(0)) at every chunk boundary and undo the prefetch.
-                const int k = 32 * (ch * CK + u) + 8 * q;
-                const u4v raw = gload<u4v>(xg, (unsigned)((pix * K + (k < K ? k : K - 8)) * 2));
-                const uint32_t keep = k < K ? 0xffffffffu : 0u;   // select, not a branch
-                const u4v msk = {raw.x & keep, raw.y & keep, raw.z & keep, raw.w & keep};
-                dst[i][u] = *reinterpret_cast<const h8*>(&msk);
+            for (int p = 0; p < 16; ++p) {
+                ps0 += p < a.nparts ? v0[p] : 0.f;
+                ps1 += p < a.nparts ? v1[p] : 0.f;
             }
         }
-    };
-    h8 xc[2][CK], xn[2][CK];
-    if (wave < NPAIR) load_chunk(wave, 0, xc);
-    // ---- everything the prologue needs is requested up front, so it costs one memory round trip: the project
-    //      weights (registers now, parked in LDS after the squeeze-excite FCs), both FC weight sets, the pool partials
-    h8 wreg[WPT];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int c = tid + 512 * i;
-        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
     }
     // FC1: thread = 4 outputs (j4) x one of 64 channel slices (k = sl, sl + 64, ...)
     constexpr int FC1_IT = (KP + 63) / 64;
@@ -2174,14 +2169,38 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
     const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
     const float brv = tid < CSP ? a.br[tid] : 0.f;
-    // ---- squeeze: pooled[k] = sum over the depthwise kernel's tiles ----
-    for (int k = tid; k < KP; k += 512) {
-        float s = 0.f;
-        if (k < K)
-            for (int p = 0; p < a.nparts; ++p) s += gload<float>(pp, (unsigned)(((b * a.nparts + p) * K + k) * 4));
-        pooled[k] = s;
-    }
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
+    auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = 32 * pr + 16 * i + m;
+            const int pix = p < HW ? p : HW - 1;
+#pragma unroll
+            for (int u = 0; u < CK; ++u) {
+                // Columns beyond K (zero-padded k-steps) re-read the row's last 8 channels: their gate and weights are
+                // zero, so no lane predicate is needed -- a per-lane branch around the load would make the compiler
+                // drain ALL outstanding loads (vmcnt(0)) at every chunk boundary and undo the prefetch.
+                const int k = 32 * (ch * CK + u) + 8 * q;
+                const u4v raw = gload<u4v>(xg, (unsigned)((pix * K + (k < K ? k : K - 8)) * 2));
+                const uint32_t keep = k < K ? 0xffffffffu : 0u;   // select, not a branch
+                const u4v msk = {raw.x & keep, raw.y & keep, raw.z & keep, raw.w & keep};
+                dst[i][u] = *reinterpret_cast<const h8*>(&msk);
+            }
+        }
+    };
+    if (tid < KP) pooled[tid] = tid < K ? ps0 : 0.f;
+    if (tid + 512 < KP) pooled[tid + 512] = tid + 512 < K ? ps1 : 0.f;
     T7_BAR();
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 3] = (float)((long long)__builtin_readcyclecounter() - tk0);
+    // bulk loads: first pixel fragments of this wave, project weights (registers now, parked in LDS after FC2)
+    h8 xc[2][CK], xn[2][CK];
+    if (wave < NPAIR) load_chunk(wave, 0, xc);
+    h8 wreg[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int c = tid + 512 * i;
+        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
+    }
     // ---- FC1: r = silu(br + psc * pooled . Wr^T) ----
     if (fc1_thr) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -2197,6 +2216,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         *reinterpret_cast<f4*>(part + sl * 32 + 4 * j4) = acc;
     }
     T7_BAR();
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
     if (tid < CSP) {
         float s = 0.f;
 #pragma unroll 8
@@ -2204,6 +2224,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         rs[tid] = silu_f(s * a.psc + brv);
     }
     T7_BAR();
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 5] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC2: gate = sigmoid(be + r . We^T) ----
     {
         float a0 = be0, a1 = be1;
@@ -2223,13 +2244,15 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
             }
         }
     }
-    T7_BAR();          // FC1 partials (aliasing wl) are dead from here
+    T7_BAR();
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 6] = (float)((long long)__builtin_readcyclecounter() - tk0);          // FC1 partials (aliasing wl) are dead from here
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
         const int c = tid + 512 * i;
         if (c < NWCH) *reinterpret_cast<h8*>(wl + c * 16) = wreg[i];
     }
     T7_BAR();
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 7] = (float)((long long)__builtin_readcyclecounter() - tk0);
     if (a.dbg_clk) tk1 = (long long)__builtin_readcyclecounter();
     // ---- project: Y[pixel][n] = sum_k (X[pixel][k] * gate[k]) W[n][k] + bias (+ residual) ----
     f4 bv[NF];

@@ -30,9 +30,9 @@ def main():
 
 def projse(bb, n):
     for blk in range(3, 11):
-        clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :3]
+        clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :8]
         med = np.median(clk, axis=0)
-        print(f"b{blk}.projse: prologue {med[0]:8.0f}  gemm {med[1]:8.0f} cycles (wave 0, last pair: k-loop {med[2]:8.0f})")
+        print(f"b{blk}.projse: prologue {med[0]:8.0f}  gemm {med[1]:8.0f} cycles (wave 0, last pair: k-loop {med[2]:8.0f}); prologue barriers at " + " ".join(f"{v:.0f}" for v in med[3:8]))
 
 
 if __name__ == "__main__":
