@@ -89,6 +89,20 @@ struct TailArgs {
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 
+// Front half of a 14x14 MBConv block for one patch per workgroup (mid14_kernel)
+struct Mid14Args {
+    const _Float16* X;        // [B][196][Cin]
+    const _Float16* wexp;     // [Ce/16][ceil(Cin/32)][64][8] expand weights, MFMA fragment order (K zero padded)
+    const float* bexp;        // [Ce]
+    const uint32_t* dwp;      // [15][Ce] depthwise taps as fp16 pairs (layout of TailBlock::dwp)
+    const float* bdw;         // [Ce]
+    _Float16* D;              // [B][196][Ce] depthwise output
+    float* pool;              // [B][Ce] pool sums
+    int B, Cin, Ce, ks;
+    int nsplit;               // workgroups per patch (each takes every nsplit-th chunk of 96 channels)
+};
+int launch_mid14(const Mid14Args& a, hipStream_t st);
+
 // Squeeze-excite + project conv of one patch per workgroup (proj_patch_kernel)
 struct ProjPatchArgs {
     const _Float16* X;        // [B][HW][K] depthwise output

@@ -2085,6 +2085,177 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// mid14_kernel: the front half (expand 1x1 + SiLU, depthwise KSDxKSD + SiLU, pool sums) of a 14x14 MBConv block for ONE
+// patch per workgroup (512 threads).  The tile/chunk kernels (mbconv_a/d) split a patch into 10-14 channel-chunk
+// workgroups that each re-load the block input and pay their own load/barrier skeleton; here the input X[196][Cin]
+// is loaded once into LDS and the workgroup walks the expanded channels in chunks of 96:
+//   expand   78 (16-channel x 16-pixel) tiles per chunk, dealt round-robin to the 8 waves; swapped MFMA, weight
+//            fragments from L2 one tile ahead, pixel fragments from LDS; silu -> E[196][96] fp16 in LDS;
+//   dw       thread = (channel, band of 3 output rows): the 7 input rows it needs become 7x7 pixel-pair dwords in
+//            registers (zero outside the image), taps on v_dot2c exactly as in tail7_kernel, the 14 outputs of a row
+//            advance together; silu; fp16 straight to the depthwise output tensor in HBM (lanes = consecutive
+//            channels: 128-byte segments); pool sums per band -> LDS -> one value per channel.
+// Output: D[B][196][CE] and pool[B][CE] -- what proj_patch_kernel consumes.
+// ---------------------------------------------------------------------------------------------
+template <int CKS, int KSD, int CE>
+__global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
+{
+    constexpr int HW = 196, CH = 96, NCHK = CE / CH, NPF = 13, NTILE = 6 * NPF;
+    constexpr int ES = CH * 2 + 16;         // bytes per E row
+    constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2;
+    static_assert(CE % CH == 0, "chunking");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;
+    float* pband = reinterpret_cast<float*>(E + HW * ES);   // [5][96]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int Cin = a.Cin;
+    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.bexp);
+    const GLOBAL_AS uint32_t* dwp = sgpr_ptr<uint32_t>(a.dwp);
+    const GLOBAL_AS float* bdw = sgpr_ptr<float>(a.bdw);
+    // Block input: each wave owns pixel fragments (13 fragments of 16 pixels: waves 0..4 own two, waves 5..7 one) and
+    // reads them straight into registers, so LDS only holds the expanded chunk and two workgroups fit a CU.
+    const int npf = wave < 5 ? 2 : 1;
+    const int pf0 = wave < 5 ? 2 * wave : wave + 5;
+    const GLOBAL_AS _Float16* xgp = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * Cin;
+    // depthwise role of this thread: channel cd of the chunk, output rows rb .. rb+2 (band 4: rows 12, 13)
+    const int band = tid / CH, cd = tid - band * CH;
+    const bool dw_thr = tid < 5 * CH;
+    const int rb = 3 * band;
+#pragma unroll 1
+    for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
+        // taps and bias of this thread's channel: requested now, used after the expand phase
+        uint32_t raw[15];
+        const int cg = chunk * CH + (dw_thr ? cd : 0);
+#pragma unroll
+        for (int i = 0; i < 3 * KSD; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * CE + cg) * 4u);
+        const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
+        // ---------------- expand: this wave's pixel fragments x the chunk's six 16-channel weight fragments ----------------
+        {
+            h8 xb[2][CKS];   // (re-read per chunk from L2: holding them across the depthwise phase costs 32 registers)
+            {
+                const GLOBAL_AS _Float16* xg = xgp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = 16 * (pf0 + (i < npf ? i : 0)) + m;
+            const int pixc = pix < HW ? pix : HW - 1;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const int kk = 32 * ks + 8 * q;
+                const u4v rawx = gload<u4v>(xg, (unsigned)((pixc * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
+                const uint32_t keep = kk < Cin ? 0xffffffffu : 0u;
+                const u4v mk = {rawx.x & keep, rawx.y & keep, rawx.z & keep, rawx.w & keep};
+                xb[i][ks] = *reinterpret_cast<const h8*>(&mk);
+            }
+        }
+    }
+            h8 wn[CKS];
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((6 * chunk) * CKS + ks) * 64 + lane) * 16));
+#pragma unroll
+            for (int nf = 0; nf < 6; ++nf) {
+                const int nfg = 6 * chunk + nf;
+                h8 wc[CKS];
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) wc[ks] = wn[ks];
+                if (nf + 1 < 6) {
+#pragma unroll
+                    for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((nfg + 1) * CKS + ks) * 64 + lane) * 16));
+                }
+                const f4 bv = gload<f4>(bexp, (unsigned)(16 * nfg + 4 * q) * 4u);
+                f4 acc[2] = {bv, bv};
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[0][ks], acc[0], 0, 0, 0);
+                    if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[1][ks], acc[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pix = 16 * (pf0 + i) + m;
+                    if (i < npf && pix < HW) {
+                        h4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[i][j]);
+                        *reinterpret_cast<h4*>(E + pix * ES + (16 * nf + 4 * q) * 2) = o;
+                    }
+                }
+            }
+        }
+        T7_BAR();
+        // ---------------- depthwise ----------------
+        float psum = 0.f;
+        {
+            constexpr int NR = 3 + 2 * R;   // input rows of a 3-row band
+            const unsigned char* col = E + 2 * cd;
+            uint32_t P[NR][7];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int iy = rb - R + r;
+                const bool rok = iy >= 0 && iy < 14;
+                const unsigned char* rowp = col + (rok ? iy : 0) * (14 * ES);
+#pragma unroll
+                for (int pp = 0; pp < 7; ++pp) {
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES);
+                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES);
+                    P[r][pp] = rok ? (lo | (hi << 16)) : 0u;
+                }
+            }
+            _Float16* dg = a.D + (size_t)b * HW * CE + chunk * CH + cd;
+#pragma unroll
+            for (int ro = 0; ro < 3; ++ro) {
+                const int oy = rb + ro;
+                if (oy < 14) {
+                    float acc[14];
+#pragma unroll
+                    for (int ox = 0; ox < 14; ++ox) acc[ox] = dbias;
+#pragma unroll
+                    for (int ky = 0; ky < KSD; ++ky) {
+                        // tap pairs of this kernel row: [parity of x][pair]; the shifted variants are derived here (per
+                        // row) instead of kept for the whole chunk -- 15 registers that decide between 3 and 4 waves/SIMD
+                        const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                        uint32_t wq[2][3];
+                        if (KSD == 5) {
+                            wq[0][0] = r0; wq[0][1] = r1; wq[0][2] = r2;
+                            wq[1][0] = r0 << 16; wq[1][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[1][2] = __builtin_amdgcn_alignbit(r2, r1, 16);
+                        } else {
+                            wq[0][0] = r0 << 16; wq[0][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[0][2] = 0u;
+                            wq[1][0] = r0; wq[1][1] = r1; wq[1][2] = 0u;
+                        }
+#pragma unroll
+                        for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+                            for (int ox = 0; ox < 14; ++ox) {
+                                const int fp = (KSD == 5 || !(ox & 1)) ? (ox >> 1) - 1 : (ox >> 1);
+                                const int xpc = fp + ip;
+                                if (xpc < 0 || xpc > 6) continue;
+                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][xpc]),
+                                                                 *reinterpret_cast<const h2*>(&wq[ox & 1][ip]), acc[ox], false);
+                            }
+                    }
+#pragma unroll
+                    for (int ox = 0; ox < 14; ++ox) {
+                        const float y = silu_scaled(acc[ox]);
+                        psum += y;
+                        if (dw_thr) dg[(size_t)(oy * 14 + ox) * CE] = (_Float16)y;
+                    }
+                }
+            }
+            if (dw_thr) pband[band * CH + cd] = psum;
+        }
+        T7_BAR();
+        if (tid < CH)
+            a.pool[(size_t)b * CE + chunk * CH + tid] =
+                (((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid]) + pband[4 * CH + tid];
+        // (the next chunk's expand writes E only after every wave passed the barrier above; pband is rewritten only
+        // after the next chunk's first barrier)
+        // (the next chunk's expand writes E only after every wave passed the barrier above; pband is rewritten only
+        // after the next chunk's first barrier)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
 // project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
@@ -2882,5 +3053,31 @@ int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
     PP_CASE(15, 7, 196, false)   // b8: 480 -> 112
     PP_CASE(21, 7, 196, true)    // b9, b10: 672 -> 112
 #undef PP_CASE
+    return -5;
+}
+
+template <int CKS, int KSD, int CE>
+static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
+{
+    const int lds = 196 * (96 * 2 + 16) + 5 * 96 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mid14_kernel<CKS, KSD, CE>), dim3(a.B, a.nsplit < 1 ? 1 : a.nsplit), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mid14(const Mid14Args& a, hipStream_t st)
+{
+    if (a.B < 1) return -14;
+    const int cks = (a.Cin + 31) / 32;
+    if (cks == 4 && a.ks == 5 && a.Ce == 672) return launch_mid14_t<4, 5, 672>(a, st);   // b9, b10
+    if (cks == 3 && a.ks == 5 && a.Ce == 480) return launch_mid14_t<3, 5, 480>(a, st);   // b8
+    if (cks == 3 && a.ks == 3 && a.Ce == 480) return launch_mid14_t<3, 3, 480>(a, st);   // b6, b7
     return -5;
 }

@@ -172,6 +172,8 @@ struct mmc_backbone {
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
     bool fuse_b0b1 = false;
+    bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
+    int mid14_last = 8;              // ... for blocks 6..mid14_last
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
     bool tail_full = false;
@@ -349,6 +351,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->fuse_stem = fuse_enabled;
     const char* pp_env = getenv("MMC_PROJSE");
     const bool projse_enabled = fuse_enabled && !(pp_env && pp_env[0] == '0');
+    const char* mid_env = getenv("MMC_MID14");
+    // MMC_MID14: 0 = off (tile/chunk kernels), 1 (default) = blocks 6..10, 2 = blocks 6..8 only
+    const int mid14_mode = !(fuse_enabled && projse_enabled) ? 0 : (mid_env ? atoi(mid_env) : 1);
+    const bool mid14_enabled = mid14_mode != 0;
+    bb->mid14 = mid14_enabled;
+    bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     const char* tail_env = getenv("MMC_TAIL");
     const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
     int H = IMG / 2;
@@ -384,8 +392,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if (tail_enabled && i >= 12 && i <= 15) {
-                // taps of tail7_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
+            if ((tail_enabled && i >= 12 && i <= 15) || (mid14_enabled && i >= 6 && i <= 10)) {
+                // taps of tail7_kernel / mid14_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
                 auto tap = [&](int c, int ky, int kx) -> _Float16 {
@@ -795,6 +803,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             STEP("stem+b0.dw", "stem_dw", launch_stem_dw(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, B.dw_w, B.dw_b,
                                                           bb->fuse_b0b1 ? y : ws.dwbuf, ws.pool_part, n, st));
             nparts = 49;
+        } else if (B.fused && bb->mid14 && i >= 6 && i <= bb->mid14_last && B.t_dwp && B.exp_frag) {
+            Mid14Args ma{};
+            ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
+            ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
+            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : 4; }
+            nparts = 1;
+            snprintf(nm, sizeof nm, "b%d.mbconv", i);
+            STEP(nm, "mid14", launch_mid14(ma, st));
         } else if (B.fused) {
             MbArgs a{};
             a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = ws.dwbuf;

@@ -202,7 +202,8 @@ def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone
     bb.close()
 
 
-@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_LANES"])
+@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2",
+                                  "MMC_LANES"])
 def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_backbone, knob, monkeypatch):
     """Each fusion has an environment switch (the separate kernels stay in the library as the reference
     schedule).  With any one of them off -- or a single lane -- the features must still pass the golden gates, and
@@ -213,7 +214,10 @@ def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_bac
     bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
     base = bb.extract(p)
     bb.close()
-    monkeypatch.setenv(knob, "1" if knob == "MMC_LANES" else "0")
+    if "=" in knob:
+        monkeypatch.setenv(*knob.split("="))
+    else:
+        monkeypatch.setenv(knob, "1" if knob == "MMC_LANES" else "0")
     bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
     try:
         got = bb.extract(p)
