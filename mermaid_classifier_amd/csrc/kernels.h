@@ -89,6 +89,22 @@ struct TailArgs {
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 
+// Block 1 front half with block 0's SE scale + project folded in (mb1_kernel)
+struct Mb1Args {
+    const _Float16* X;        // [B][112][112][32] block 0's depthwise output
+    const _Float16* pre_w;    // [64][8] block 0's project conv as one MFMA fragment
+    const float* pre_b;       // [16]
+    const float* pre_gate;    // [B][32] block 0's squeeze-excite gate
+    const _Float16* wexp;     // [96][32] expand weights, natural rows, K-permuted (slot 8q+j <- channel 4q+j, j < 4)
+    const float* bexp;        // [96]
+    const float* wdw;         // [9][96] depthwise taps (fp32, tap-major)
+    const float* bdw;         // [96]
+    _Float16* D;              // [B][56][56][96]
+    float* pool;              // [B][14][96]
+    int B;
+};
+int launch_mb1(const Mb1Args& a, hipStream_t st);
+
 // Front half of a 14x14 MBConv block for one patch per workgroup (mid14_kernel)
 struct Mid14Args {
     const _Float16* X;        // [B][196][Cin]

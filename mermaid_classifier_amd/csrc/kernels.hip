@@ -2256,6 +2256,132 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// mb1_kernel: block 1 (112x112 -> 56x56: block 0's SE scale + project 32 -> 16, expand 16 -> 96, depthwise 3x3 stride 2)
+// in the thread = channel x window-in-registers style of mid14_kernel.  One workgroup (512 threads) = (patch, output
+// tile of 8 rows x 28 columns, chunk of 32 expanded channels); its input window is 17 x 57 positions.
+//   expand   wave w owns the 16-position fragments w, w+8, ...: block 0's depthwise output is read straight into
+//            registers (all loads first: one round trip), scaled by block 0's gate, projected by ONE MFMA (K-permuted
+//            expand weights, as in mbconv_a_kernel PRE), expanded by two MFMAs, silu -> E[976][32] fp16 in LDS; positions
+//            outside the image are written as zeros (padding lives in the expanded domain).
+//   dw       thread = (channel, output row, half of the 28 columns): 3 input rows x 15 pixel pairs in registers,
+//            two v_dot2c per kernel row and output ((k0,k1) on pair j, (k2,0) on pair j+1), silu, fp16 to HBM,
+//            pool sums through LDS -> pool[patch][tile][96].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
+{
+    constexpr int NPOS = 17 * 57, NPF = (NPOS + 15) / 16, ES = 80;   // 969 positions, 61 fragments, bytes per E row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;
+    float* pred = reinterpret_cast<float*>(smem + NPF * 16 * ES);    // [16][32] pool partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int ty = tile >> 1, tx = tile & 1;
+    const int oy0 = 8 * ty, ox0 = 28 * tx, iy0 = 16 * ty, ix0 = 56 * tx;
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * 112 * 112 * 32;
+    // ---------------- expand (with block 0's gate + project in front) ----------------
+    {
+        u4v xr[8];
+        bool ok[8];
+        int pos[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pf = wave + 8 * i;
+            const int p = 16 * pf + m;
+            const int r = p / 57, c = p - r * 57;
+            const int iy = iy0 + r, ix = ix0 + c;
+            ok[i] = pf < NPF && p < NPOS && iy < 112 && ix < 112;
+            pos[i] = p;
+            xr[i] = gload<u4v>(xg, (unsigned)((((ok[i] ? iy : 0) * 112 + (ok[i] ? ix : 0)) * 32 + 8 * q) * 2));
+        }
+        const h8 wpre = *reinterpret_cast<const h8*>(a.pre_w + lane * 8);
+        const f4 bpre = *reinterpret_cast<const f4*>(a.pre_b + 4 * q);
+        const f4 g0 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q);
+        const f4 g1 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q + 4);
+        h8 wexp[2];
+        f4 bexp[2];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            wexp[nf] = *reinterpret_cast<const h8*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));
+            bexp[nf] = *reinterpret_cast<const f4*>(a.bexp + chunk * 32 + 16 * nf + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (wave + 8 * i >= NPF) continue;   // wave-uniform
+            const uint4 xin = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+            const uint4 gx = gate_h8(xin, g0, g1);
+            const f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&gx), bpre, 0, 0, 0);
+            h8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[j] = (_Float16)x1[j];   // block 0's output, rounded as the separate path stores it
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wexp[nf], xb, bexp[nf], 0, 0, 0);
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = ok[i] ? (_Float16)silu_scaled(acc[j]) : (_Float16)0.0f;
+                *reinterpret_cast<h4*>(E + pos[i] * ES + (16 * nf + 4 * q) * 2) = o;
+            }
+        }
+    }
+    T7_BAR();
+    // ---------------- depthwise 3x3 stride 2 ----------------
+    {
+        const int c = tid & 31, orow = (tid >> 5) & 7, half = tid >> 8;
+        const int cg = chunk * 32 + c;
+        uint32_t wq[3][2];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float k0 = a.wdw[(size_t)(ky * 3 + 0) * 96 + cg], k1 = a.wdw[(size_t)(ky * 3 + 1) * 96 + cg],
+                        k2 = a.wdw[(size_t)(ky * 3 + 2) * 96 + cg];
+            h2 w0 = {(_Float16)k0, (_Float16)k1}, w1 = {(_Float16)k2, (_Float16)0.0f};
+            wq[ky][0] = *reinterpret_cast<uint32_t*>(&w0);
+            wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
+        }
+        const float dbias = a.bdw[cg];
+        const unsigned char* col = E + 2 * c;
+        uint32_t P[3][15];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const unsigned char* rowp = col + ((2 * orow + ky) * 57 + 28 * half) * ES;
+#pragma unroll
+            for (int pp = 0; pp < 15; ++pp) {
+                const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES);
+                const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES);
+                P[ky][pp] = lo | (hi << 16);
+            }
+        }
+        float acc[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) acc[j] = dbias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
+                                                    acc[j], false);
+        float psum = 0.f;
+        _Float16* dg = a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const float y = silu_scaled(acc[j]);
+            psum += y;
+            dg[(size_t)j * 96] = (_Float16)y;
+        }
+        pred[(tid >> 5) * 32 + c] = psum;
+    }
+    T7_BAR();
+    if (tid < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += pred[w * 32 + tid];
+        a.pool[((size_t)b * 14 + tile) * 96 + chunk * 32 + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
 // project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
@@ -3080,4 +3206,19 @@ int launch_mid14(const Mid14Args& a, hipStream_t st)
     if (cks == 3 && a.ks == 5 && a.Ce == 480) return launch_mid14_t<3, 5, 480>(a, st);   // b8
     if (cks == 3 && a.ks == 3 && a.Ce == 480) return launch_mid14_t<3, 3, 480>(a, st);   // b6, b7
     return -5;
+}
+
+int launch_mb1(const Mb1Args& a, hipStream_t st)
+{
+    if (a.B < 1) return -15;
+    const int lds = 61 * 16 * 80 + 16 * 32 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mb1_kernel, dim3(14, 3, a.B), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
 }

@@ -172,6 +172,7 @@ struct mmc_backbone {
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
     bool fuse_b0b1 = false;
+    bool mb1 = false;                // block 1 on mb1_kernel (window-in-registers depthwise) instead of mbconv_a PRE
     bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
     int mid14_last = 8;              // ... for blocks 6..mid14_last
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
@@ -641,6 +642,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     {
         const char* e = getenv("MMC_FUSE_B0");
         const BlockW& B1 = bb->blk[1];
+        { const char* m1 = getenv("MMC_MB1"); bb->mb1 = !(m1 && m1[0] == '0'); }
         bb->fuse_b0b1 = !(e && e[0] == '0') && bb->fuse_stem && bb->b0_pre_w && bb->b1_exp_pre && B1.fused && !B1.use_d && B1.f_TH == 8 &&
                         B1.f_TWo == 8 && B1.f_CC == 48 && B1.f_tw == 2 && B1.f_pb == 1 && !B1.f_wlds && B1.f_npair == 3;
     }
@@ -828,7 +830,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                 STEP(nm, fl, launch_mbconv_d(a, st));
             } else {
                 snprintf(fl, sizeof fl, "mbconv_a<%d,%d,%d,%d,%d,%d,%d,%d>", a.ks, a.stride, a.tw, a.ksteps, a.npair, a.CC, a.pb, a.wlds);
-                if (i == 1 && bb->fuse_b0b1) {
+                if (i == 1 && bb->fuse_b0b1 && bb->mb1) {
+                    Mb1Args m1{};
+                    m1.X = y; m1.pre_w = bb->b0_pre_w; m1.pre_b = bb->blk[0].project.b; m1.pre_gate = ws.gate; m1.wexp = bb->b1_exp_pre;
+                    m1.bexp = B.expand.b; m1.wdw = B.dw_w; m1.bdw = B.dw_b; m1.D = ws.dwbuf; m1.pool = ws.pool_part; m1.B = n;
+                    nparts = 14;
+                    snprintf(nm, sizeof nm, "b0.project+b1.mbconv");
+                    STEP(nm, "mb1", launch_mb1(m1, st));
+                } else if (i == 1 && bb->fuse_b0b1) {
                     a.X = y; a.Cin = 32; a.Wexp = bb->b1_exp_pre;   // block 0's depthwise output; its gate is in ws.gate
                     snprintf(nm, sizeof nm, "b0.project+b1.mbconv");
                     STEP(nm, "mbconv_a_pre", launch_mbconv_pre(a, bb->b0_pre_w, bb->blk[0].project.b, ws.gate, st));
