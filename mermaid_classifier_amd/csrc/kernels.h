@@ -105,6 +105,19 @@ struct Mb1Args {
 };
 int launch_mb1(const Mb1Args& a, hipStream_t st);
 
+// Front half of a stride-1 MBConv block on 14x28 output tiles (mbt_kernel: b2, b4)
+struct MbtArgs {
+    const _Float16* X;        // [B][H][H][Cin]
+    const _Float16* wexp;     // [Ce/16][ceil(Cin/32)][64][8] expand weights, MFMA fragment order
+    const float* bexp;        // [Ce]
+    const uint32_t* dwp;      // [15][Ce] depthwise taps as fp16 pairs (layout of TailBlock::dwp)
+    const float* bdw;         // [Ce]
+    _Float16* D;              // [B][H][H][Ce]
+    float* pool;              // [B][tiles][Ce]
+    int B, H, Cin, Ce, ks;
+};
+int launch_mbt(const MbtArgs& a, hipStream_t st);
+
 // Front half of a 14x14 MBConv block for one patch per workgroup (mid14_kernel)
 struct Mid14Args {
     const _Float16* X;        // [B][196][Cin]

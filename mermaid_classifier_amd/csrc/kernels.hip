@@ -2382,6 +2382,163 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// mbt_kernel: front half (expand + depthwise stride 1 + pool sums) of the 56x56 and 28x28 blocks (b2, b4) in the
+// window-in-registers style of mid14_kernel, with spatial tiling.  One workgroup (512 threads) = (patch, output tile of
+// 14 rows x 28 columns, chunk of 48 expanded channels).  The tile's input window (14 + 2R rows, 28 or 30 columns, even
+// aligned) is expanded into E[window position][48] in LDS -- positions outside the image as zeros -- from pixel
+// fragments read straight into registers; then thread = (channel, band of 3 output rows, half of the 28 columns) holds
+// its (3 + 2R) x 9 pixel-pair window in registers and runs the taps on v_dot2c as tail7/mid14 do.
+// Template: KSD depthwise size, CKS k-steps of the block input, CE expanded channels, HIMG image size.
+// ---------------------------------------------------------------------------------------------
+template <int KSD, int CKS, int CE, int HIMG>
+__global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
+{
+    constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2, NROWS = 14 + 2 * R, CH = 48, ES = CH * 2 + 16;
+    constexpr int WW = HIMG == 28 ? 28 : 30;              // window columns (even aligned)
+    constexpr int NPOS = NROWS * WW, NPF = (NPOS + 15) / 16;
+    static_assert(NPF <= 32, "four fragments per wave");
+    constexpr int TX = HIMG / 28, NR = 3 + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;                                            // [NPF*16][ES]
+    float* pred = reinterpret_cast<float*>(smem + NPF * 16 * ES);       // [10][48]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const int oy0 = 14 * ty, ox0 = 28 * tx;
+    const int wx0 = ox0 >= 2 ? ox0 - 2 : 0;               // even
+    const int Cin = a.Cin;
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HIMG * HIMG * Cin;
+    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    // ---------------- expand ----------------
+    {
+        u4v xr[4][CKS];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = 16 * (wave + 8 * i) + m;
+            const int r = p / WW, c = p - r * WW;
+            const int iy = oy0 - R + r, ix = wx0 + c;
+            ok[i] = p < NPOS && iy >= 0 && iy < HIMG && ix < HIMG;
+            const int row = ok[i] ? iy * HIMG + ix : 0;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const int kk = 32 * ks + 8 * q;
+                xr[i][ks] = gload<u4v>(xg, (unsigned)((row * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
+            }
+        }
+        h8 wa[3][CKS];
+        f4 ba[3];
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) {
+            const int nfg = 3 * chunk + nf;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
+            ba[nf] = *reinterpret_cast<const f4*>(a.bexp + 16 * nfg + 4 * q);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (wave + 8 * i >= NPF) continue;   // wave-uniform
+            h8 xb[CKS];
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const uint32_t keep = (32 * ks + 8 * q < Cin) ? 0xffffffffu : 0u;   // zero-padded K columns: select, not branch
+                const u4v mk = {xr[i][ks].x & keep, xr[i][ks].y & keep, xr[i][ks].z & keep, xr[i][ks].w & keep};
+                xb[ks] = *reinterpret_cast<const h8*>(&mk);
+            }
+            const int p = 16 * (wave + 8 * i) + m;
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                f4 acc = ba[nf];
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[nf][ks], xb[ks], acc, 0, 0, 0);
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = ok[i] ? (_Float16)silu_scaled(acc[j]) : (_Float16)0.0f;
+                *reinterpret_cast<h4*>(E + p * ES + (16 * nf + 4 * q) * 2) = o;
+            }
+        }
+    }
+    T7_BAR();
+    // ---------------- depthwise ----------------
+    {
+        const int c = tid % CH, rest = tid / CH;            // rest: 0..9 for the 480 working threads
+        const bool dw_thr = rest < 10;
+        const int band = rest % 5, half = rest / 5;
+        const int rb = 3 * band;
+        const int cg = chunk * CH + c;
+        uint32_t raw[15];
+#pragma unroll
+        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg];
+        const float dbias = a.bdw[cg];
+        // window pair columns of this half: local pair l (0..8) <-> window pair (cbase/2 - 1 + l); cbase is even
+        const int cbase = ox0 + 14 * half - wx0;
+        const int pb = (cbase >> 1) - 1;
+        const unsigned char* col = E + 2 * c;
+        uint32_t P[NR][9];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int wr = rb + r < NROWS ? rb + r : NROWS - 1;     // (band 4 has two output rows: its last window row is unused)
+            const unsigned char* rowp = col + (wr * WW) * ES;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) {
+                const int wp = pb + l;
+                const bool pok = wp >= 0 && wp < WW / 2;
+                const int wpc = pok ? wp : 0;
+                const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * wpc) * ES);
+                const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * wpc + 1) * ES);
+                P[r][l] = pok ? (lo | (hi << 16)) : 0u;
+            }
+        }
+        float psum = 0.f;
+        _Float16* dg = a.D + (((size_t)b * HIMG + oy0 + rb) * HIMG + ox0 + 14 * half) * CE + cg;
+#pragma unroll
+        for (int ro = 0; ro < 3; ++ro) {
+            if (rb + ro < 14) {
+                float acc[14];
+#pragma unroll
+                for (int j = 0; j < 14; ++j) acc[j] = dbias;
+#pragma unroll
+                for (int ky = 0; ky < KSD; ++ky) {
+                    const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                    uint32_t wq[2][3];
+                    if (KSD == 5) {
+                        wq[0][0] = r0; wq[0][1] = r1; wq[0][2] = r2;
+                        wq[1][0] = r0 << 16; wq[1][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[1][2] = __builtin_amdgcn_alignbit(r2, r1, 16);
+                    } else {
+                        wq[0][0] = r0 << 16; wq[0][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[0][2] = 0u;
+                        wq[1][0] = r0; wq[1][1] = r1; wq[1][2] = 0u;
+                    }
+#pragma unroll
+                    for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+                        for (int j = 0; j < 14; ++j) {
+                            // local pair of output column j: k5 -> (j>>1) + ip; k3 -> even j: (j>>1) + ip, odd j: (j>>1) + 1 + ip
+                            const int l = (KSD == 5 || !(j & 1)) ? (j >> 1) + ip : (j >> 1) + 1 + ip;
+                            acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][l]),
+                                                            *reinterpret_cast<const h2*>(&wq[j & 1][ip]), acc[j], false);
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 14; ++j) {
+                    const float y = silu_scaled(acc[j]);
+                    psum += y;
+                    if (dw_thr) dg[((size_t)ro * HIMG + j) * CE] = (_Float16)y;
+                }
+            }
+        }
+        if (dw_thr) pred[rest * CH + c] = psum;
+    }
+    T7_BAR();
+    if (tid < CH) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 10; ++w) s += pred[w * CH + tid];
+        a.pool[((size_t)b * gridDim.x + tile) * CE + chunk * CH + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
 // project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
@@ -3221,4 +3378,29 @@ int launch_mb1(const Mb1Args& a, hipStream_t st)
     hipLaunchKernelGGL(mb1_kernel, dim3(14, 3, a.B), dim3(512), lds, st, a);
     LAUNCH_CHECK();
     return 0;
+}
+
+template <int KSD, int CKS, int CE, int HIMG>
+static int launch_mbt_t(const MbtArgs& a, hipStream_t st)
+{
+    constexpr int NROWS = 14 + 2 * (KSD / 2), WW = HIMG == 28 ? 28 : 30, NPF = (NROWS * WW + 15) / 16;
+    const int lds = NPF * 16 * 112 + 10 * 48 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbt_kernel<KSD, CKS, CE, HIMG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mbt_kernel<KSD, CKS, CE, HIMG>), dim3((HIMG / 14) * (HIMG / 28), CE / 48, a.B), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mbt(const MbtArgs& a, hipStream_t st)
+{
+    if (a.B < 1) return -16;
+    if (a.H == 56 && a.ks == 3 && a.Cin == 24 && a.Ce == 144) return launch_mbt_t<3, 1, 144, 56>(a, st);   // b2
+    if (a.H == 28 && a.ks == 5 && a.Cin == 40 && a.Ce == 240) return launch_mbt_t<5, 2, 240, 28>(a, st);   // b4
+    return -5;
 }
