@@ -161,6 +161,16 @@ struct mmc_backbone {
         hipEvent_t done = nullptr;
     };
     Lane lanes[4];
+    // optional (MMC_GRAPH=1): a pass over device-resident buffers is captured once per (input, output, n) into a HIP graph
+    // and replayed -- the ~26 launches per lane then cost one graph launch
+    struct GraphEntry { const void* in; float* out; int n; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    bool use_graph = false;
+    int graph_warm = 0;
+    const void* last_in = nullptr;   // a (buffers, n) combination is captured when it repeats: callers that reuse their
+    float* last_out = nullptr;       // buffers (bench, BatchedExtractor, torch's caching allocator) get the graph, others plain launches
+    int last_cnt = -1;
+    hipStream_t gstream = nullptr;
     int nlanes = 1, lane_cap = 0;
     hipEvent_t fork = nullptr;
     uint8_t* in_stage = nullptr;
@@ -280,6 +290,8 @@ extern "C" void mmc_backbone_destroy(mmc_backbone* bb)
         if (bb->lanes[l].done) hipEventDestroy(bb->lanes[l].done);
     }
     if (bb->fork) hipEventDestroy(bb->fork);
+    for (auto& g : bb->graphs) hipGraphExecDestroy(g.exec);
+    if (bb->gstream) hipStreamDestroy(bb->gstream);
     delete bb;
 }
 
@@ -310,6 +322,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->max_batch = max_batch;
     const char* keep = getenv("MMC_KEEP_ACTIVATIONS");
     bb->keep = keep && keep[0] == '1';
+    { const char* e = getenv("MMC_GRAPH"); bb->use_graph = !(e && e[0] == '0') && !bb->keep; }
     { const char* e = getenv("MMC_SE_SMALL"); bb->se_small = !(e && e[0] == '0'); }
     if (bb->keep) { int r__ = dev_alloc(bb, &bb->dbg_clk, (size_t)max_batch * 8); if (r__) { mmc_backbone_destroy(bb); return r__; } }
     std::vector<uint64_t> table(2 * (size_t)nt);
@@ -989,6 +1002,42 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
     return 0;
 }
 
+// forward_pass through a cached HIP graph (device-resident buffers only); falls back to plain launches on any error
+static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hipStream_t st)
+{
+    if (!bb->use_graph) return forward_pass(bb, pin, n, pout, st, nullptr);
+    for (auto& g : bb->graphs)
+        if (g.in == pin && g.out == pout && g.n == n) {
+            HIP_TRY(hipGraphLaunch(g.exec, st));
+            return 0;
+        }
+    const bool repeat = bb->last_in == pin && bb->last_out == pout && bb->last_cnt == n;
+    bb->last_in = pin; bb->last_out = pout; bb->last_cnt = n;
+    if (bb->graph_warm < 2 || !repeat || bb->graphs.size() >= 8) {   // first passes un-captured: lazy per-kernel attribute setup happens there
+        ++bb->graph_warm;
+        return forward_pass(bb, pin, n, pout, st, nullptr);
+    }
+    if (!bb->gstream && hipStreamCreateWithFlags(&bb->gstream, hipStreamNonBlocking) != hipSuccess) {
+        bb->use_graph = false;
+        return forward_pass(bb, pin, n, pout, st, nullptr);
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(bb->gstream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    int r = ok ? forward_pass(bb, pin, n, pout, bb->gstream, nullptr) : 0;
+    if (ok) ok = hipStreamEndCapture(bb->gstream, &graph) == hipSuccess && r == 0 && graph;
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) hipGraphDestroy(graph);
+    if (!ok) {
+        (void)hipGetLastError();
+        bb->use_graph = false;
+        return forward_pass(bb, pin, n, pout, st, nullptr);
+    }
+    bb->graphs.push_back({pin, pout, n, exec});
+    HIP_TRY(hipGraphLaunch(exec, st));
+    return 0;
+}
+
 extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
                                     unsigned flags, void* hip_stream)
 {
@@ -1008,7 +1057,7 @@ extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64
             pin = bb->in_stage;
         }
         float* pout = (flags & MMC_OUT_HOST) ? bb->out_stage : out_features + (size_t)off * FEAT;
-        int r = forward_pass(bb, pin, cur, pout, st, nullptr);
+        int r = run_pass(bb, pin, cur, pout, st);   // (host buffers go through the fixed staging buffers: same graph every call)
         if (r) return r;
         if (flags & MMC_OUT_HOST)
             HIP_TRY(hipMemcpyAsync(out_features + (size_t)off * FEAT, bb->out_stage, (size_t)cur * FEAT * sizeof(float),

@@ -202,7 +202,7 @@ def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone
     bb.close()
 
 
-@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MB1", "MMC_MBT=1",
+@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MB1", "MMC_MBT=1", "MMC_GRAPH",
                                   "MMC_LANES"])
 def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_backbone, knob, monkeypatch):
     """Each fusion has an environment switch (the separate kernels stay in the library as the reference
@@ -228,3 +228,28 @@ def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_bac
     assert rel_l2(got, base).max() < TOL_NATURAL
     if knob == "MMC_LANES":
         assert np.array_equal(got, base)          # lanes only split the batch: bitwise identical
+
+
+def test_graph_replay_is_bitwise_identical_to_plain_launches(checkpoint_path, monkeypatch):
+    """A pass over buffers that repeat is captured into a HIP graph on the third call and replayed afterwards
+    (mmc_api.cpp run_pass); replay, plain launches (MMC_GRAPH=0) and a call with fresh buffers must agree bitwise."""
+    import torch
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    p = torch.from_numpy(ref.natural_patches(12, seed=5)).cuda()
+    out = torch.empty((12, 1280), dtype=torch.float32, device="cuda")
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=12)
+    runs = []
+    for _ in range(6):                       # same buffers every time: plain, plain, capture + launch, replay ...
+        out.zero_()
+        bb.extract(p, out=out)
+        runs.append(out.cpu().numpy().copy())
+    fresh = bb.extract(p.clone()).cpu().numpy()
+    bb.close()
+    monkeypatch.setenv("MMC_GRAPH", "0")
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=12)
+    plain = bb.extract(p).cpu().numpy()
+    bb.close()
+    for r in runs:
+        assert np.array_equal(r, plain)
+    assert np.array_equal(fresh, plain)
