@@ -72,7 +72,10 @@ size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb);
 
 /* patches: n x 224 x 224 x 3 u8 (HWC, RGB).  out_features: n x feature_dim fp32, row i = patch i.
  * flags: MMC_IN_HOST | MMC_OUT_HOST select host pointers; default both device pointers.
- * Asynchronous on `hip_stream` unless MMC_OUT_HOST is set. */
+ * Asynchronous on `hip_stream` unless MMC_OUT_HOST is set.  A handle is used from one thread at a time (the
+ * reference's forward path is single-threaded: scripts/build_feature_bucket.py, "one extractor instance per process").
+ * When the same (patches, out_features, n) combination comes in repeatedly the pass is captured into a HIP graph
+ * once and replayed on `hip_stream` afterwards (env MMC_GRAPH=0 disables); results are identical either way. */
 int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
                          unsigned flags, void* hip_stream);
 
