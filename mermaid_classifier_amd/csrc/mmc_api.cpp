@@ -167,9 +167,10 @@ struct mmc_backbone {
     std::vector<GraphEntry> graphs;
     bool use_graph = false;
     int graph_warm = 0;
-    const void* last_in = nullptr;   // a (buffers, n) combination is captured when it repeats: callers that reuse their
-    float* last_out = nullptr;       // buffers (bench, BatchedExtractor, torch's caching allocator) get the graph, others plain launches
-    int last_cnt = -1;
+    // a (buffers, n) combination is captured the second time it is seen (ring of recent combinations): callers that
+    // reuse their buffers (bench, BatchedExtractor's chunks, torch's caching allocator) get graphs, others plain launches
+    struct SeenKey { const void* in; float* out; int n; };
+    std::vector<SeenKey> seen;
     hipStream_t gstream = nullptr;
     int nlanes = 1, lane_cap = 0;
     hipEvent_t fork = nullptr;
@@ -1011,8 +1012,12 @@ static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hi
             HIP_TRY(hipGraphLaunch(g.exec, st));
             return 0;
         }
-    const bool repeat = bb->last_in == pin && bb->last_out == pout && bb->last_cnt == n;
-    bb->last_in = pin; bb->last_out = pout; bb->last_cnt = n;
+    bool repeat = false;
+    for (auto& k : bb->seen) repeat = repeat || (k.in == pin && k.out == pout && k.n == n);
+    if (!repeat) {
+        if (bb->seen.size() >= 16) bb->seen.erase(bb->seen.begin());
+        bb->seen.push_back({pin, pout, n});
+    }
     if (bb->graph_warm < 2 || !repeat || bb->graphs.size() >= 8) {   // first passes un-captured: lazy per-kernel attribute setup happens there
         ++bb->graph_warm;
         return forward_pass(bb, pin, n, pout, st, nullptr);
