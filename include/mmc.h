@@ -25,7 +25,9 @@ extern "C" {
 #define MMC_ERR_HIP 3      /* HIP runtime failure (RuntimeError) */
 #define MMC_ERR_NOMEM 4
 
-#define MMC_ARCH_B0 0
+#define MMC_ARCH_B0 0   /* efficientnet-b0: the network pyspacer's EfficientNetExtractor builds (the reference path) */
+#define MMC_ARCH_B4 1   /* efficientnet-b4 (width 1.4, depth 1.8) on 224x224 patches: BASELINE.json configs[4]; not in the
+                         * reference; runs on the generic per-layer kernels (no fused schedule yet), feature_dim 1792 */
 
 /* memory-kind flags for mmc_backbone_extract / mmc_head_predict / mmc_crop_patches */
 #define MMC_IN_DEVICE 0u
@@ -34,6 +36,7 @@ extern "C" {
 #define MMC_OUT_HOST 2u  /* outputs are host memory; the call synchronises the stream before returning */
 
 #define MMC_FEATURE_DIM_B0 1280
+#define MMC_FEATURE_DIM_B4 1792
 #define MMC_PATCH 224
 
 typedef struct mmc_backbone mmc_backbone;
@@ -63,7 +66,7 @@ int mmc_device_count(void);     /* number of visible HIP devices (0 when none) *
 int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device, int max_batch,
                         mmc_backbone** out);
 void mmc_backbone_destroy(mmc_backbone* bb);
-int mmc_feature_dim(const mmc_backbone* bb);            /* 1280 for B0 */
+int mmc_feature_dim(const mmc_backbone* bb);            /* 1280 for B0, 1792 for B4 */
 int mmc_backbone_max_batch(const mmc_backbone* bb);
 /* A pass is split into this many sub-batches that run concurrently on internal HIP streams (forked from and
  * joined to `hip_stream`); env MMC_LANES overrides the default of 2.  Results do not depend on it. */

@@ -45,29 +45,37 @@ def _current_stream_ptr(device_index: int) -> int:
 
 
 class Backbone:
-    """EfficientNet-B0 feature extractor resident on one MI355X.
+    """EfficientNet feature extractor resident on one MI355X.
 
     ``weights`` may be a path / byte stream of ``efficientnet.pt`` (pyspacer layout) or an
-    already-loaded state dict ({key: array-like}, ``module.`` prefix optional)."""
+    already-loaded state dict ({key: array-like}, ``module.`` prefix optional).
+    ``arch``: None = efficientnet-b0 for a checkpoint stream (what the reference path loads) and
+    detected from the stem width for a state dict; "b0" / "b4" to insist."""
 
-    def __init__(self, weights, device=0, max_batch: int = 256):
+    def __init__(self, weights, device=0, max_batch: int = 256, arch=None):
         lib = _lib.lib()
         if isinstance(weights, dict):
             sd = {}
             for k, v in weights.items():
                 k = k[7:] if k.startswith("module.") else k
                 sd[k] = np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float64)
-            want = _weights.expected_shapes()
+            A = _weights.get_arch(arch) if arch is not None else _weights.detect_arch(sd)
+            want = _weights.expected_shapes(A)
             missing = sorted(k for k in want if k not in sd)
             if missing:
                 raise _weights.WeightsError(f"state dict is missing keys: {missing[:10]}")
-            blob = _weights.pack_backbone({k: sd[k] for k in want})
+            bad = sorted(f"{k}: {tuple(sd[k].shape)} != {want[k]}" for k in want if tuple(sd[k].shape) != want[k])
+            if bad:
+                raise _weights.WeightsError(f"efficientnet-{A.name} state dict has wrong shapes: {bad[:10]}")
+            blob = _weights.pack_backbone({k: sd[k] for k in want}, A)
         else:
-            blob = _weights.pack_from_stream(weights)
+            A = _weights.get_arch(arch)
+            blob = _weights.pack_from_stream(weights, A)
+        self.arch = A.name
         self.device_index = _device_index(device)
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _lib.check(lib.mmc_backbone_create(C.cast(buf, C.c_void_p), len(blob), 0, self.device_index,
+        _lib.check(lib.mmc_backbone_create(C.cast(buf, C.c_void_p), len(blob), A.arch_id, self.device_index,
                                            int(max_batch), C.byref(self._h)))
         self.max_batch = int(max_batch)
         self.feature_dim = lib.mmc_feature_dim(self._h)

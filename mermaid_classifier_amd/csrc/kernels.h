@@ -30,7 +30,8 @@ struct DwArgs {
     float* pool_part;    // [B][parts][C]
     int B, H, W, C, Ho, Wo, pad_t, pad_l;
     int ks, stride, tw;
-    int CG, S, iters, parts;
+    int CG, S, iters, parts;   // CG = channel groups (of 8) per workgroup
+    int nz;                    // channel splits (gridDim.z): CG * nz * 8 == C
 };
 
 struct MbArgs {
@@ -156,7 +157,7 @@ int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 int launch_mbconv_pre(const MbArgs& a, const _Float16* pre_w, const float* pre_b, const float* pre_gate, hipStream_t st);
 int launch_mbconv_d(const MbArgs& a, hipStream_t st);   // dot2 depthwise variant (pair-interleaved LDS tile)
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
-                hipStream_t st);
+                int channels, hipStream_t st);
 int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, const float* Wdw,
                    const float* bdw, _Float16* out, float* pool_part, int B, hipStream_t st);
 int launch_pw_gemm(const GemmArgs& a, hipStream_t st);
@@ -165,6 +166,8 @@ int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, co
                    const float* WeP, const float* be, float* gate, hipStream_t st);
 int launch_se_small(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
                     const float* we, const float* be, float* gate, hipStream_t st);
+int launch_se_wide(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
+                   const float* we, const float* be, float* gate, hipStream_t st);
 int launch_mlp_layer(const float* X, int M, int K, const float* W, const float* bias, float* Y, int N, bool relu,
                      hipStream_t st);
 int launch_calibrate(const float* logits, int M, int K, const float* a, const float* b, float* proba, int32_t* argmax,

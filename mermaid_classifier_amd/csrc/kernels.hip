@@ -48,11 +48,12 @@ static __device__ __forceinline__ float silu_scaled(float t)
 #define STEM_IN (2 * STEM_TILE + 1)   // 33
 #define STEM_ROWH 104                 // halves per LDS row (99 used), keeps rows 16-B aligned
 
+template <int NT>   // NT fragments of 16 output channels: 2 for B0 (32), 3 for B4 (48)
 __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restrict__ patches,  // [B][224][224][3]
-                                                        const _Float16* __restrict__ w,        // [32][32] (n, kslot)
-                                                        const float* __restrict__ bias,        // [32]
+                                                        const _Float16* __restrict__ w,        // [16 NT][32] (n, kslot)
+                                                        const float* __restrict__ bias,        // [16 NT]
                                                         const float* __restrict__ padval,      // [3]  255*mean-128
-                                                        _Float16* __restrict__ out)            // [B][112][112][32]
+                                                        _Float16* __restrict__ out)            // [B][112][112][16 NT]
 {
     __shared__ __attribute__((aligned(16))) _Float16 tile[STEM_IN * STEM_ROWH];
     const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
@@ -85,14 +86,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
     const int lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     // weight fragments (A operand): rows = output channels
-    h8 wf[2];
+    h8 wf[NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
-    float bs[8];
+    for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
+    float bs[4 * NT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bs[t * 4 + j] = bias[q * 8 + t * 4 + j];
+        for (int j = 0; j < 4; ++j) bs[t * 4 + j] = bias[q * 4 * NT + t * 4 + j];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         const int oyl = wave * 4 + f;  // local output row
@@ -107,19 +108,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const uint8_t* __restric
 #pragma unroll
             for (int j = 0; j < 3; ++j) a[j] = tile[(2 * oyl + j) * STEM_ROWH + 6 * m + 8];
         }
-        f4 acc[2];
+        f4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
             acc[t] = (f4){bs[t * 4], bs[t * 4 + 1], bs[t * 4 + 2], bs[t * 4 + 3]};  // bias = accumulator init
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], a, acc[t], 0, 0, 0);
         }
         const int oy = ty * 16 + oyl, ox = tx * 16 + m;
-        h8 o;
+        _Float16* op = out + (((size_t)b * 112 + oy) * 112 + ox) * (16 * NT) + q * 4 * NT;
+        if (NT == 2) {
+            h8 o;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_scaled(acc[t][j]);
-        *reinterpret_cast<h8*>(out + (((size_t)b * 112 + oy) * 112 + ox) * 32 + q * 8) = o;
+                for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_scaled(acc[t][j]);
+            *reinterpret_cast<h8*>(op) = o;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[t][j]);
+                *reinterpret_cast<h4*>(op + 4 * t) = o;
+            }
+        }
     }
 }
 
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
 // plus per-(patch, channel) partial sums of the fp32 SiLU outputs for squeeze-excite.
 // Thread = 8 channels x TW consecutive output pixels of one row; channel-group index is the fastest
 // thread index so neighbouring lanes read neighbouring 16-byte vectors (coalesced NHWC).
-// blockDim.x = CG*S (CG = C/8 channel groups, S strips per pass).  Partial sums are reduced through
+// blockDim.x = CG*S (CG = channel groups of 8 per workgroup = C/8/gridDim.z, S strips per pass).  Partial sums are reduced through
 // LDS in a fixed order and written to pool_part[patch][blockIdx.x][C] (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------
 template <int KS, int ST, int TW>
@@ -354,13 +366,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
                                                      int H, int W, int C, int Ho, int Wo, int pad_t, int pad_l,
                                                      int CG, int S, int iters)
 {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [S][C]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [S][8 CG]
     const int tid = threadIdx.x;
     const int cg = tid % CG, s = tid / CG;
     const int b = blockIdx.y;
     const int strips_per_row = Wo / TW;
     const int nstrips = Ho * strips_per_row;
-    const int c0 = cg * 8;
+    const int coff = blockIdx.z * CG * 8;   // layers wider than 2048 channels split their channel groups over z
+    const int CL = CG * 8;
+    const int c0 = coff + cg * 8;
     const _Float16* inb = in + (size_t)b * H * W * C + c0;
     _Float16* outb = out + (size_t)b * Ho * Wo * C + c0;
     float bs[8];
@@ -429,12 +443,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[s * C + c0 + j] = pooled[j];
+    for (int j = 0; j < 8; ++j) red[s * CL + cg * 8 + j] = pooled[j];
     __syncthreads();
-    for (int c = tid; c < C; c += blockDim.x) {
+    for (int c = tid; c < CL; c += blockDim.x) {
         float sum = 0.f;
-        for (int ss = 0; ss < S; ++ss) sum += red[ss * C + c];
-        pool_part[((size_t)b * gridDim.x + blockIdx.x) * C + c] = sum;
+        for (int ss = 0; ss < S; ++ss) sum += red[ss * CL + c];
+        pool_part[((size_t)b * gridDim.x + blockIdx.x) * C + coff + c] = sum;
     }
 }
 
@@ -721,6 +735,49 @@ __global__ __launch_bounds__(256) void se_small_kernel(const float* __restrict__
         float acc = be[tid];
         for (int j = 0; j < Cs; ++j) acc = __builtin_fmaf(rs[j], we[(size_t)tid * Cs + j], acc);
         gate[(size_t)b * C + tid] = sigmoid_f(acc);
+    }
+}
+
+// se_wide_kernel: the same computation without the size limits (any C, any Cs; pooled vector and squeeze units in
+// dynamic LDS) -- the squeeze-excite of the generic per-layer schedule (EfficientNet-B4: C <= 2688, Cs <= 112).
+__global__ __launch_bounds__(256) void se_wide_kernel(const float* __restrict__ pool_part, int nparts, int C, int Cs,
+                                                      const float* __restrict__ wr,   // [Cs][C], carries 1/(HW log2e)
+                                                      const float* __restrict__ br,   // [Cs]
+                                                      const float* __restrict__ we,   // [C][Cs]
+                                                      const float* __restrict__ be,   // [C]
+                                                      float* __restrict__ gate)       // [B][C]
+{
+    extern __shared__ float se_sm[];
+    float* pooled = se_sm;       // [C]
+    float* rs = se_sm + C;       // [Cs]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        const float* pp = pool_part + (size_t)b * nparts * C + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int p = 0;
+        for (; p + 3 < nparts; p += 4) {
+            s0 += pp[(size_t)p * C];
+            s1 += pp[(size_t)(p + 1) * C];
+            s2 += pp[(size_t)(p + 2) * C];
+            s3 += pp[(size_t)(p + 3) * C];
+        }
+        for (; p < nparts; ++p) s0 += pp[(size_t)p * C];
+        pooled[c] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = __builtin_fmaf(pooled[c], wr[(size_t)j * C + c], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) rs[j] = silu_f(s + br[j]);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float acc = be[c];
+        for (int j = 0; j < Cs; ++j) acc = __builtin_fmaf(rs[j], we[(size_t)c * Cs + j], acc);
+        gate[(size_t)b * C + c] = sigmoid_f(acc);
     }
 }
 
@@ -3012,10 +3069,12 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     } while (0)
 
 int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, _Float16* out, int B,
-                hipStream_t st)
+                int channels, hipStream_t st)
 {
     dim3 grid(7, 7, B);
-    hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), 0, st, patches, w, bias, padval, out);
+    if (channels == 32) hipLaunchKernelGGL(stem_conv_kernel<2>, grid, dim3(256), 0, st, patches, w, bias, padval, out);
+    else if (channels == 48) hipLaunchKernelGGL(stem_conv_kernel<3>, grid, dim3(256), 0, st, patches, w, bias, padval, out);
+    else return -13;
     LAUNCH_CHECK();
     return 0;
 }
@@ -3093,9 +3152,11 @@ int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
 template <int KS, int ST, int TW>
 static int launch_dw_t(const DwArgs& a, hipStream_t st)
 {
-    dim3 grid(a.parts, a.B, 1);
+    const int nz = a.nz > 0 ? a.nz : 1;
+    if (a.CG * nz * 8 != a.C || a.CG * a.S > 256 || a.CG * a.S < 1) return -14;
+    dim3 grid(a.parts, a.B, nz);
     dim3 block(a.CG * a.S);
-    const size_t shm = (size_t)a.S * a.C * sizeof(float);
+    const size_t shm = (size_t)a.S * a.CG * 8 * sizeof(float);
     hipLaunchKernelGGL((dwconv_kernel<KS, ST, TW>), grid, block, shm, st, a.in, a.wt, a.bias, a.out, a.pool_part, a.H,
                        a.W, a.C, a.Ho, a.Wo, a.pad_t, a.pad_l, a.CG, a.S, a.iters);
     LAUNCH_CHECK();
@@ -3127,6 +3188,16 @@ int launch_se_small(const float* pool_part, int nparts, int B, int C, int Cs, co
 {
     if (C > 256 || Cs > 16 || B < 1) return -12;
     hipLaunchKernelGGL(se_small_kernel, dim3(B), dim3(256), 0, st, pool_part, nparts, C, Cs, wr, br, we, be, gate);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_se_wide(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
+                   const float* we, const float* be, float* gate, hipStream_t st)
+{
+    if (B < 1 || C < 1 || Cs < 1 || (size_t)(C + Cs) * 4 > 60000) return -12;
+    hipLaunchKernelGGL(se_wide_kernel, dim3(B), dim3(256), (size_t)(C + Cs) * sizeof(float), st, pool_part, nparts, C, Cs, wr, br,
+                       we, be, gate);
     LAUNCH_CHECK();
     return 0;
 }

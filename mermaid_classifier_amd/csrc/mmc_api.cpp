@@ -56,7 +56,39 @@ static const BlockDef B0_BLOCKS[16] = {
     {5, 1, 6, 40, 40},  {3, 2, 6, 40, 80},  {3, 1, 6, 80, 80},   {3, 1, 6, 80, 80},
     {5, 1, 6, 80, 112}, {5, 1, 6, 112, 112}, {5, 1, 6, 112, 112}, {5, 2, 6, 112, 192},
     {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {5, 1, 6, 192, 192}, {3, 1, 6, 192, 320}};
-static const int STEM_CH = 32, HEAD_IN = 320, FEAT = 1280, IMG = 224;
+static const int IMG = 224;
+// The published family: B0's stage table under compound scaling (widths to multiples of 8, never below 90 % of the scaled
+// value; repeats rounded up).  B0 is the network the reference path runs; B4 (width 1.4, depth 1.8, BASELINE.json
+// configs[4]) does not exist in the reference and runs on the generic per-layer kernels.
+struct ArchDef { int stem = 32, head_in = 320, feat = 1280; std::vector<BlockDef> blocks; };
+static int round_filters(int c, double width)
+{
+    const double v = c * width;
+    int n = (int)(v + 4) / 8 * 8;
+    if (n < 8) n = 8;
+    if (n < 0.9 * v) n += 8;
+    return n;
+}
+static ArchDef make_arch(int arch)
+{
+    ArchDef A;
+    if (arch == MMC_ARCH_B0) {
+        A.blocks.assign(B0_BLOCKS, B0_BLOCKS + 16);
+        return A;
+    }
+    const double width = 1.4, depth = 1.8;   // MMC_ARCH_B4
+    static const int STAGES[7][6] = {{1, 3, 1, 1, 32, 16},  {2, 3, 2, 6, 16, 24},   {2, 5, 2, 6, 24, 40}, {3, 3, 2, 6, 40, 80},
+                                     {3, 5, 1, 6, 80, 112}, {4, 5, 2, 6, 112, 192}, {1, 3, 1, 6, 192, 320}};
+    A.stem = round_filters(32, width);
+    for (auto& st : STAGES) {
+        const int cin = round_filters(st[4], width), cout = round_filters(st[5], width);
+        const int reps = (int)std::ceil(depth * st[0] - 1e-9);
+        for (int r = 0; r < reps; ++r) A.blocks.push_back({st[1], r == 0 ? st[2] : 1, st[3], r == 0 ? cin : cout, cout});
+    }
+    A.head_in = A.blocks.back().cout;
+    A.feat = round_filters(1280, width);
+    return A;
+}
 // Scaled activation domain (kernels.hip, silu_scaled): every SiLU output is stored times log2(e).
 // Producers (stem, expand, depthwise, head) get weights/bias times LOG2E, consumers times 1/LOG2E;
 // for the depthwise taps the two cancel, so only its bias is scaled.
@@ -106,7 +138,7 @@ struct BlockW {
     float *se_wrp = nullptr, *se_wep = nullptr;   // fragment-ordered fp32 squeeze-excite weights
     float *se_wr_nat = nullptr, *se_we_nat = nullptr, *se_br_nat = nullptr;   // natural fp32 copies for se_small_kernel (C <= 256)
     // depthwise launch geometry
-    int tw = 0, CG = 0, S = 0, iters = 0, parts = 0;
+    int tw = 0, CG = 0, S = 0, iters = 0, parts = 0, nz = 1;
     // fused expand+depthwise (mbconv_a_kernel) geometry; fused == false -> separate GEMM + dwconv
     bool fused = false;
     _Float16* exp_nat = nullptr;  // [ce][32*f_ksteps] natural rows
@@ -147,9 +179,10 @@ struct Saved {
 
 struct mmc_backbone {
     int device = 0, max_batch = 0;
+    int arch = MMC_ARCH_B0, nblk = 16, stem_ch = 32, head_in = 320, feat = 1280;
     _Float16* stem_w = nullptr;
     float *stem_b = nullptr, *stem_pad = nullptr;
-    BlockW blk[16];
+    std::vector<BlockW> blk;
     PwLayer head;
     // workspace: one lane per internal stream.  A pass over n patches is split into `nlanes` independent
     // sub-batches that run concurrently on their own HIP streams, so the latency-bound small launches of
@@ -302,7 +335,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     if (!out) return fail(MMC_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!packed || nbytes < 16) return fail(MMC_ERR_WEIGHTS, "weights blob is empty");
-    if (arch != MMC_ARCH_B0) return fail(MMC_ERR_ARG, "unsupported arch %d (only MMC_ARCH_B0)", arch);
+    if (arch != MMC_ARCH_B0 && arch != MMC_ARCH_B4) return fail(MMC_ERR_ARG, "unsupported arch %d (MMC_ARCH_B0 or MMC_ARCH_B4)", arch);
     if (max_batch < 1 || max_batch > 4096) return fail(MMC_ERR_ARG, "max_batch %d out of range [1,4096]", max_batch);
     const uint8_t* base = static_cast<const uint8_t*>(packed);
     uint32_t hdr[4];
@@ -321,6 +354,11 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     mmc_backbone* bb = new mmc_backbone();
     bb->device = device;
     bb->max_batch = max_batch;
+    const ArchDef AD = make_arch(arch);
+    const bool is_b0 = arch == MMC_ARCH_B0;
+    const int STEM_CH = AD.stem, HEAD_IN = AD.head_in, FEAT = AD.feat, NBLK = (int)AD.blocks.size();
+    bb->arch = arch; bb->nblk = NBLK; bb->stem_ch = STEM_CH; bb->head_in = HEAD_IN; bb->feat = FEAT;
+    bb->blk.resize(NBLK);
     const char* keep = getenv("MMC_KEEP_ACTIVATIONS");
     bb->keep = keep && keep[0] == '1';
     { const char* e = getenv("MMC_GRAPH"); bb->use_graph = !(e && e[0] == '0') && !bb->keep; }
@@ -336,17 +374,18 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
 #define TRY_OR_FREE(expr)                          \
     do { int r__ = (expr); if (r__) { mmc_backbone_destroy(bb); return r__; } } while (0)
 
-    // ---- stem: [32][27] folded (ky,kx,c), bias[32], padval[3] ----
+    // ---- stem: [Cstem][27] folded (ky,kx,c), bias[Cstem], padval[3] ----
     {
         TAKE(w, (size_t)STEM_CH * 27, "stem.weight");
         TAKE(b, STEM_CH, "stem.bias");
         TAKE(pv, 3, "stem.padval");
-        std::vector<_Float16> wp(32 * 32, (_Float16)0.0f);
-        for (int t = 0; t < 2; ++t)
+        const int snt = STEM_CH / 16;   // output fragments: lane quarter q owns channels q*4*snt + 4t + j
+        std::vector<_Float16> wp((size_t)STEM_CH * 32, (_Float16)0.0f);
+        for (int t = 0; t < snt; ++t)
             for (int q = 0; q < 4; ++q)
                 for (int j = 0; j < 4; ++j) {
                     const int prow = t * 16 + 4 * q + j;
-                    const int c = q * 8 + 4 * t + j;
+                    const int c = q * 4 * snt + 4 * t + j;
                     const float* wc = w + (size_t)c * 27;
                     for (int qq = 0; qq < 3; ++qq)           // kernel row qq, bytes 0..7 of its 9-byte run
                         for (int jj = 0; jj < 8; ++jj) wp[prow * 32 + qq * 8 + jj] = (_Float16)(float)(wc[qq * 9 + jj] * LOG2E);
@@ -361,7 +400,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     }
     // ---- blocks ----
     const char* fuse_env = getenv("MMC_FUSE");
-    const bool fuse_enabled = !(fuse_env && fuse_env[0] == '0');
+    const bool fuse_enabled = is_b0 && !(fuse_env && fuse_env[0] == '0');   // the fused kernels are shaped for B0's layers
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
     bb->fuse_stem = fuse_enabled;
@@ -381,9 +420,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     int H = IMG / 2;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
     int max_c = 0;
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NBLK; ++i) {
         BlockW& B = bb->blk[i];
-        B.d = B0_BLOCKS[i];
+        B.d = AD.blocks[i];
         B.H = H;
         B.ce = B.d.cin * B.d.e;
         B.cs = B.d.cin / 4 > 1 ? B.d.cin / 4 : 1;
@@ -404,9 +443,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.ce * B.d.k * B.d.k, nm);  // [ce][k][k]
             TAKE(b, B.ce, nm);
             const int kk = B.d.k * B.d.k;
+            // the taps see a log2(e)-scaled input (stem or expand output) and produce a scaled output: the factors cancel --
+            // except for an expand-less block fed by a project conv (B4's block 1), whose input is in the plain domain
+            const double tsc = (B.has_expand || i == 0) ? 1.0 : LOG2E;
             std::vector<float> wt((size_t)kk * B.ce);
             for (int c = 0; c < B.ce; ++c)
-                for (int t = 0; t < kk; ++t) wt[(size_t)t * B.ce + c] = w[(size_t)c * kk + t];
+                for (int t = 0; t < kk; ++t) wt[(size_t)t * B.ce + c] = (float)(w[(size_t)c * kk + t] * tsc);
             TRY_OR_FREE(dev_upload(bb, &B.dw_w, wt));
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
@@ -440,8 +482,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             // activations.
             B.cs4 = (B.cs + 3) / 4 * 4;
             const double psc = 1.0 / ((double)B.Ho * B.Ho * LOG2E);
-            const int ng = B.ce / 16;
-            std::vector<float> wrp((size_t)ng * 3 * 64 * 4, 0.f), wep((size_t)ng * 3 * 64 * 4, 0.f);
+            const int ng = is_b0 ? B.ce / 16 : 0;   // (se_fused_kernel's packing: B0 only, Cs <= 48)
+            std::vector<float> wrp((size_t)ng * 3 * 64 * 4 + 4, 0.f), wep((size_t)ng * 3 * 64 * 4 + 4, 0.f);
             for (int g = 0; g < ng; ++g)
                 for (int t = 0; t < 3; ++t)
                     for (int ln = 0; ln < 64; ++ln)
@@ -470,7 +512,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 TRY_OR_FREE(dev_upload(bb, &B.pp_br, brp));
                 B.pp_csp = csp;
             }
-            if (B.ce <= 256 && B.cs <= 16) {   // early blocks: light per-patch squeeze-excite kernel
+            if ((B.ce <= 256 && B.cs <= 16) || !is_b0) {   // early blocks: light per-patch squeeze-excite kernel; generic schedule: se_wide
                 std::vector<float> wrn((size_t)B.cs * B.ce);
                 for (size_t e = 0; e < wrn.size(); ++e) wrn[e] = (float)(wr[e] * psc);
                 TRY_OR_FREE(dev_upload(bb, &B.se_wr_nat, wrn));
@@ -479,7 +521,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             }
             TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
             TRY_OR_FREE(dev_upload(bb, &B.se_wep, wep));
-            std::vector<float> brs(48, 0.f);
+            std::vector<float> brs(B.cs > 48 ? B.cs : 48, 0.f);
             for (int j = 0; j < B.cs; ++j) brs[j] = br[j];
             TRY_OR_FREE(dev_upload(bb, &B.se_br, brs));
             TRY_OR_FREE(dev_upload(bb, &B.se_be, std::vector<float>(be, be + B.ce)));
@@ -533,12 +575,15 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         // depthwise geometry
         B.tw = (B.Ho % 4 == 0) ? 4 : (B.Ho % 7 == 0 && B.Ho <= 7 ? 7 : 2);
         B.CG = B.ce / 8;
+        B.nz = 1;
+        while (B.CG / B.nz > 256 || B.CG % B.nz) ++B.nz;   // layers wider than 2048 channels: split the channel groups
+        B.CG /= B.nz;
         B.S = 256 / B.CG > 0 ? 256 / B.CG : 1;
         const int strips = B.Ho * (B.Ho / B.tw);
         const int passes = (strips + B.S - 1) / B.S;
         B.iters = passes >= 8 ? 4 : 1;
         B.parts = (passes + B.iters - 1) / B.iters;
-        if (B.has_expand && fuse_enabled) {
+        if (B.has_expand && fuse_enabled && i < 16) {
             FuseCfg fc = B0_FUSE[i];
             if (const char* ov = getenv("MMC_FUSE_CFG")) {   // "i:TH,TWo,CC;..." experiment override
                 char key[16];
@@ -628,7 +673,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         TAKE(w, (size_t)FEAT * HEAD_IN, "head.weight");
         TAKE(b, FEAT, "head.bias");
         TRY_OR_FREE(pack_pw(bb, &bb->head, w, b, FEAT, HEAD_IN, 4, LOG2E, LOG2E));
-        if (tail_enabled) {   // the same weights in plain fragment order [80][10][64][8] for tail7's head phase
+        if (tail_enabled && HEAD_IN % 32 == 0) {   // the same weights in plain fragment order [80][10][64][8] for tail7's head phase
             std::vector<_Float16> wf((size_t)FEAT * HEAD_IN);
             for (int c = 0; c < FEAT; ++c)
                 for (int k = 0; k < HEAD_IN; ++k)
@@ -638,8 +683,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         }
     }
     if (tail_enabled) {
-        bool ok = true;
-        for (int i = 12; i <= 15; ++i) {
+        bool ok = NBLK == 16;
+        for (int i = 12; i <= 15 && ok; ++i) {
             const BlockW& B = bb->blk[i];
             ok = ok && B.exp_frag && B.t_wr && B.t_dwp && B.t_wproj && B.H == 7 && B.d.s == 1 && B.d.cin == 192 && B.ce == 1152;
         }
@@ -707,7 +752,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     return MMC_OK;
 }
 
-extern "C" int mmc_feature_dim(const mmc_backbone* bb) { return bb ? FEAT : 0; }
+extern "C" int mmc_feature_dim(const mmc_backbone* bb) { return bb ? bb->feat : 0; }
 extern "C" int mmc_backbone_max_batch(const mmc_backbone* bb) { return bb ? bb->max_batch : 0; }
 extern "C" int mmc_backbone_lanes(const mmc_backbone* bb) { return bb ? bb->nlanes : 0; }
 extern "C" size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb) { return bb ? bb->ws_bytes : 0; }
@@ -779,12 +824,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
     _Float16* y = ws.act1;
     const bool stem_fused = bb->fuse_stem;   // then the stem tensor never exists in HBM (no "stem" activation to keep)
     if (!stem_fused) {
-        STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, st));
-        if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * STEM_CH, true, st); if (r) return r; }
+        STEP("stem", "stem_conv", launch_stem(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, x, n, bb->stem_ch, st));
+        if (bb->keep) { int r = save_act(bb, "stem", x, (size_t)n * 112 * 112 * bb->stem_ch, true, st); if (r) return r; }
     }
     bool tail_done = false;
     const bool se_small_enabled = bb->se_small;
-    for (int i = 0; i < 16; ++i) {
+    const int FEAT = bb->feat;
+    (void)FEAT;
+    for (int i = 0; i < bb->nblk; ++i) {
         if (i == 12 && bb->tail_tab) {
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
             if (!bb->keep) {
@@ -881,7 +928,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             DwArgs d{};
             d.in = dw_in; d.wt = B.dw_w; d.bias = B.dw_b; d.out = ws.dwbuf; d.pool_part = ws.pool_part;
             d.B = n; d.H = B.H; d.W = B.H; d.C = B.ce; d.Ho = B.Ho; d.Wo = B.Ho; d.pad_t = B.pad; d.pad_l = B.pad;
-            d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts;
+            d.ks = B.d.k; d.stride = B.d.s; d.tw = B.tw; d.CG = B.CG; d.S = B.S; d.iters = B.iters; d.parts = B.parts; d.nz = B.nz;
             snprintf(nm, sizeof nm, "b%d.dw", i);
             char dl[48];
             snprintf(dl, sizeof dl, "dwconv<%d,%d,%d>", d.ks, d.stride, d.tw);
@@ -941,7 +988,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             continue;
         }
         snprintf(nm, sizeof nm, "b%d.gate", i);
-        if (B.se_wr_nat && se_small_enabled)
+        if (bb->arch != MMC_ARCH_B0)
+            STEP(nm, "se_wide", launch_se_wide(ws.pool_part, nparts, n, B.ce, B.cs, B.se_wr_nat, B.se_br_nat, B.se_we_nat, B.se_be,
+                                               ws.gate, st));
+        else if (B.se_wr_nat && se_small_enabled)
             STEP(nm, "se_small", launch_se_small(ws.pool_part, nparts, n, B.ce, B.cs, B.se_wr_nat, B.se_br_nat, B.se_we_nat, B.se_be,
                                                  ws.gate, st));
         else
@@ -955,7 +1005,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (bb->keep) { int r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st); if (r) return r; }
         _Float16* t = x; x = y; y = t;
     }
-    const int HWh = bb->blk[15].Ho * bb->blk[15].Ho;
+    const int HWh = bb->blk[bb->nblk - 1].Ho * bb->blk[bb->nblk - 1].Ho;
     if (tail_done) {
         // features already written by tail7_kernel
     } else if (bb->tail_full) {   // per-tensor mode: the head phase of tail7_kernel on its own
@@ -982,7 +1032,7 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
                                          for (int off = 0; off < n; off += bb->lane_cap) {
                                              const int cur = n - off < bb->lane_cap ? n - off : bb->lane_cap;
                                              int r = forward_lane(bb, bb->lanes[0], patches_dev + (size_t)off * IMG * IMG * 3, cur,
-                                                                  out_dev + (size_t)off * FEAT, st, prof);
+                                                                  out_dev + (size_t)off * bb->feat, st, prof);
                                              if (r) return r;
                                          }
                                          return 0;
@@ -995,7 +1045,7 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
         if (cur <= 0) break;
         mmc_backbone::Lane& L = bb->lanes[l];
         HIP_TRY(hipStreamWaitEvent(L.stream, bb->fork, 0));
-        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * FEAT, L.stream, prof);
+        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * bb->feat, L.stream, prof);
         if (r) return r;
         HIP_TRY(hipEventRecord(L.done, L.stream));
         HIP_TRY(hipStreamWaitEvent(st, L.done, 0));
@@ -1061,6 +1111,7 @@ extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64
             HIP_TRY(hipMemcpyAsync(bb->in_stage, pin, (size_t)cur * psz, hipMemcpyHostToDevice, st));
             pin = bb->in_stage;
         }
+        const size_t FEAT = (size_t)bb->feat;
         float* pout = (flags & MMC_OUT_HOST) ? bb->out_stage : out_features + (size_t)off * FEAT;
         int r = run_pass(bb, pin, cur, pout, st);   // (host buffers go through the fixed staging buffers: same graph every call)
         if (r) return r;

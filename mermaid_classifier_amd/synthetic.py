@@ -14,13 +14,14 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .weights import B0_BLOCKS, FEATURE_DIM
+from .weights import get_arch
 
 NUM_FC_CLASSES = 1275  # pyspacer builds the net with num_classes=1275 [RECALL R3]; _fc is unused
 
 
-def checkpoint_keys() -> Dict[str, tuple]:
+def checkpoint_keys(arch=None) -> Dict[str, tuple]:
     """Every key of the checkpoint's state dict (without ``module.``), in module order."""
+    A = get_arch(arch)
     keys: Dict[str, tuple] = {}
 
     def bn(prefix: str, c: int):
@@ -30,9 +31,9 @@ def checkpoint_keys() -> Dict[str, tuple]:
         keys[prefix + ".running_var"] = (c,)
         keys[prefix + ".num_batches_tracked"] = ()
 
-    keys["_conv_stem.weight"] = (32, 3, 3, 3)
-    bn("_bn0", 32)
-    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+    keys["_conv_stem.weight"] = (A.stem, 3, 3, 3)
+    bn("_bn0", A.stem)
+    for i, (k, s, e, cin, cout) in enumerate(A.blocks):
         p = f"_blocks.{i}."
         ce = cin * e
         if e != 1:
@@ -47,18 +48,18 @@ def checkpoint_keys() -> Dict[str, tuple]:
         keys[p + "_se_expand.bias"] = (ce,)
         keys[p + "_project_conv.weight"] = (cout, ce, 1, 1)
         bn(p + "_bn2", cout)
-    keys["_conv_head.weight"] = (FEATURE_DIM, 320, 1, 1)
-    bn("_bn1", FEATURE_DIM)
-    keys["_fc.weight"] = (NUM_FC_CLASSES, FEATURE_DIM)
+    keys["_conv_head.weight"] = (A.feature_dim, A.head_in, 1, 1)
+    bn("_bn1", A.feature_dim)
+    keys["_fc.weight"] = (NUM_FC_CLASSES, A.feature_dim)
     keys["_fc.bias"] = (NUM_FC_CLASSES,)
     return keys
 
 
-def synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
+def synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]] = None, arch=None) -> Dict[str, np.ndarray]:
     """{key: ndarray}; running stats default to mean 0 / var 1 unless ``bn_stats`` supplies them."""
     rng = np.random.default_rng(seed)
     sd: Dict[str, np.ndarray] = {}
-    for k, shp in checkpoint_keys().items():
+    for k, shp in checkpoint_keys(arch).items():
         if k.endswith("num_batches_tracked"):
             sd[k] = np.zeros((), dtype=np.int64)
         elif k.endswith("running_mean"):
@@ -78,7 +79,7 @@ def synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]
     if bn_stats is not None:
         for k, v in bn_stats.items():
             if k not in sd or tuple(sd[k].shape) != tuple(np.shape(v)):
-                raise KeyError(f"bn_stats entry {k!r} does not match the B0 layout")
+                raise KeyError(f"bn_stats entry {k!r} does not match the {get_arch(arch).name} layout")
             sd[k] = np.asarray(v, dtype=np.float32).copy()
     return sd
 

@@ -11,17 +11,21 @@ keys carry a ``module.`` (DataParallel) prefix; lukemelas EfficientNet-PyTorch n
 ``_fc`` (1275 x 1280) is present and unused by ``extract_features``.
 
 Blob (all tensors fp32, natural layouts; the library does its own MFMA packing):
-  header  magic "MMCW", u32 version=1, u32 arch=0, u32 n_tensors
+  header  magic "MMCW", u32 version=1, u32 arch (0 = B0, 1 = B4), u32 n_tensors
   table   n_tensors x (u64 offset, u64 nbytes), offsets 256-B aligned
-  order   stem.weight [32][27] (ky,kx,c fastest; BN scale and 1/(255 std) folded)
-          stem.bias [32]   (BN shift + folded mean term)
+  order   stem.weight [Cstem][27] (ky,kx,c fastest; BN scale and 1/(255 std) folded)
+          stem.bias [Cstem]   (BN shift + folded mean term)
           stem.padval [3]  (255*mean - 128: the u8-128 value that normalises to 0)
-          per block i=0..15:
+          per block i:
             [expand.weight [Ce][Cin], expand.bias [Ce]]       (absent when expand ratio is 1)
             dw.weight [Ce][k][k], dw.bias [Ce]
             se.reduce.weight [Cs][Ce], se.reduce.bias [Cs], se.expand.weight [Ce][Cs], se.expand.bias [Ce]
             project.weight [Cout][Ce], project.bias [Cout]
-          head.weight [1280][320], head.bias [1280]
+          head.weight [F][Chead_in], head.bias [F]          (B0: 1280 x 320, B4: 1792 x 448)
+
+Architectures: ``b0`` is the network pyspacer's EfficientNetExtractor builds (the reference path);
+``b4`` (width 1.4, depth 1.8 of the same published family, still on 224x224 patches) is BASELINE.json
+configs[4] -- it does not exist in the reference and runs on the library's generic per-layer kernels.
 """
 
 from __future__ import annotations
@@ -45,17 +49,74 @@ B0_BLOCKS: List[Tuple[int, int, int, int, int]] = [
     (5, 1, 6, 192, 192), (5, 1, 6, 192, 192), (5, 1, 6, 192, 192), (3, 1, 6, 192, 320),
 ]
 
+# The published EfficientNet family: B0's stage table scaled by (width, depth) coefficients.
+# (repeats, kernel, stride, expand, cin, cout)
+_B0_STAGES = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+              (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
 
-def expected_shapes() -> Dict[str, tuple]:
+
+def _round_filters(c: int, width: float, divisor: int = 8) -> int:
+    c = c * width
+    new = max(divisor, int(c + divisor / 2) // divisor * divisor)
+    if new < 0.9 * c:
+        new += divisor
+    return int(new)
+
+
+class Arch:
+    """Stem width, block list and feature width of one member of the family."""
+
+    def __init__(self, name: str, arch_id: int, width: float, depth: float):
+        self.name, self.arch_id = name, arch_id
+        self.stem = _round_filters(32, width)
+        self.blocks: List[Tuple[int, int, int, int, int]] = []
+        for rep, k, s, e, cin, cout in _B0_STAGES:
+            cin, cout = _round_filters(cin, width), _round_filters(cout, width)
+            for r in range(int(np.ceil(depth * rep))):
+                self.blocks.append((k, s if r == 0 else 1, e, cin if r == 0 else cout, cout))
+        self.head_in = self.blocks[-1][4]
+        self.feature_dim = _round_filters(1280, width)
+
+
+ARCHS: Dict[str, Arch] = {"b0": Arch("b0", 0, 1.0, 1.0), "b4": Arch("b4", 1, 1.4, 1.8)}
+assert ARCHS["b0"].blocks == B0_BLOCKS and ARCHS["b0"].feature_dim == FEATURE_DIM
+
+
+def get_arch(arch) -> Arch:
+    if isinstance(arch, Arch):
+        return arch
+    if arch in (None, 0):
+        return ARCHS["b0"]
+    if arch == 1:
+        return ARCHS["b4"]
+    try:
+        return ARCHS[str(arch).lower().replace("efficientnet-", "")]
+    except KeyError:
+        raise ValueError(f"unknown architecture {arch!r} (known: {sorted(ARCHS)})") from None
+
+
+def detect_arch(sd) -> Arch:
+    """Which family member a state dict holds, from the stem width."""
+    w = sd.get("_conv_stem.weight", sd.get("module._conv_stem.weight"))
+    if w is None:
+        raise WeightsError("state dict has no _conv_stem.weight")
+    for a in ARCHS.values():
+        if int(np.shape(w)[0]) == a.stem:
+            return a
+    raise WeightsError(f"stem width {np.shape(w)[0]} matches none of {sorted(ARCHS)}")
+
+
+def expected_shapes(arch=None) -> Dict[str, tuple]:
+    A = get_arch(arch)
     shapes: Dict[str, tuple] = {}
 
     def bn(prefix, c):
         for suffix in ("weight", "bias", "running_mean", "running_var"):
             shapes[f"{prefix}.{suffix}"] = (c,)
 
-    shapes["_conv_stem.weight"] = (32, 3, 3, 3)
-    bn("_bn0", 32)
-    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+    shapes["_conv_stem.weight"] = (A.stem, 3, 3, 3)
+    bn("_bn0", A.stem)
+    for i, (k, s, e, cin, cout) in enumerate(A.blocks):
         p = f"_blocks.{i}."
         ce = cin * e
         cs = max(1, int(cin * 0.25))
@@ -70,8 +131,8 @@ def expected_shapes() -> Dict[str, tuple]:
         shapes[p + "_se_expand.bias"] = (ce,)
         shapes[p + "_project_conv.weight"] = (cout, ce, 1, 1)
         bn(p + "_bn2", cout)
-    shapes["_conv_head.weight"] = (FEATURE_DIM, 320, 1, 1)
-    bn("_bn1", FEATURE_DIM)
+    shapes["_conv_head.weight"] = (A.feature_dim, A.head_in, 1, 1)
+    bn("_bn1", A.feature_dim)
     return shapes
 
 
@@ -79,9 +140,10 @@ class WeightsError(ValueError):
     """The checkpoint does not look like pyspacer's efficientnet-b0 weights."""
 
 
-def load_checkpoint(stream) -> Dict[str, np.ndarray]:
+def load_checkpoint(stream, arch=None) -> Dict[str, np.ndarray]:
     """Read an ``efficientnet.pt`` byte stream / path -> {key: fp64 ndarray} with the
-    ``module.`` prefix stripped.  Fails loudly, listing unexpected / missing keys."""
+    ``module.`` prefix stripped.  Fails loudly, listing unexpected / missing keys.
+    ``arch`` None = efficientnet-b0, the network the reference path loads."""
     import torch
 
     if isinstance(stream, (bytes, bytearray)):
@@ -99,14 +161,15 @@ def load_checkpoint(stream) -> Dict[str, np.ndarray]:
     for k, v in net.items():
         k = k[7:] if k.startswith("module.") else k
         sd[k] = v.detach().cpu().numpy()
-    want = expected_shapes()
+    A = get_arch(arch)
+    want = expected_shapes(A)
     ignorable = lambda k: k.endswith("num_batches_tracked") or k.startswith("_fc.")  # noqa: E731
     missing = sorted(k for k in want if k not in sd)
     unexpected = sorted(k for k in sd if k not in want and not ignorable(k))
     bad_shape = sorted(f"{k}: {tuple(sd[k].shape)} != {want[k]}" for k in want if k in sd and tuple(sd[k].shape) != want[k])
     if missing or unexpected or bad_shape:
         raise WeightsError(
-            "efficientnet-b0 checkpoint mismatch: "
+            f"efficientnet-{A.name} checkpoint mismatch: "
             f"missing={missing[:10]}{'...' if len(missing) > 10 else ''} "
             f"unexpected={unexpected[:10]}{'...' if len(unexpected) > 10 else ''} "
             f"bad_shape={bad_shape[:10]}")
@@ -119,8 +182,9 @@ def _bn_scale_shift(sd, prefix):
     return scale, shift
 
 
-def fold(sd: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray]]:
+def fold(sd: Dict[str, np.ndarray], arch=None) -> List[Tuple[str, np.ndarray]]:
     """BN folding (fp64) -> ordered list of (name, fp32 array) in blob order."""
+    A = get_arch(arch)
     out: List[Tuple[str, np.ndarray]] = []
     mean = np.asarray(IMAGENET_MEAN)
     std = np.asarray(IMAGENET_STD)
@@ -129,10 +193,10 @@ def fold(sd: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray]]:
     w = sd["_conv_stem.weight"].transpose(0, 2, 3, 1)        # [n][ky][kx][c]
     s_c = 1.0 / (255.0 * std)
     t_c = (128.0 - 255.0 * mean) / (255.0 * std)
-    out.append(("stem.weight", (w * s_c * g[:, None, None, None]).reshape(32, 27)))
+    out.append(("stem.weight", (w * s_c * g[:, None, None, None]).reshape(A.stem, 27)))
     out.append(("stem.bias", g * (w * t_c).sum(axis=(1, 2, 3)) + h))
     out.append(("stem.padval", 255.0 * mean - 128.0))
-    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+    for i, (k, s, e, cin, cout) in enumerate(A.blocks):
         p = f"_blocks.{i}."
         ce = cin * e
         if e != 1:
@@ -151,13 +215,14 @@ def fold(sd: Dict[str, np.ndarray]) -> List[Tuple[str, np.ndarray]]:
         out.append((f"b{i}.project.weight", sd[p + "_project_conv.weight"].reshape(cout, ce) * g[:, None]))
         out.append((f"b{i}.project.bias", h))
     g, h = _bn_scale_shift(sd, "_bn1")
-    out.append(("head.weight", sd["_conv_head.weight"].reshape(FEATURE_DIM, 320) * g[:, None]))
+    out.append(("head.weight", sd["_conv_head.weight"].reshape(A.feature_dim, A.head_in) * g[:, None]))
     out.append(("head.bias", h))
     return [(n, np.ascontiguousarray(a, dtype=np.float32)) for n, a in out]
 
 
-def pack_backbone(sd: Dict[str, np.ndarray]) -> bytes:
-    tensors = fold(sd)
+def pack_backbone(sd: Dict[str, np.ndarray], arch=None) -> bytes:
+    A = get_arch(arch)
+    tensors = fold(sd, A)
     n = len(tensors)
     table_end = 16 + 16 * n
     off = (table_end + 255) // 256 * 256
@@ -166,7 +231,7 @@ def pack_backbone(sd: Dict[str, np.ndarray]) -> bytes:
         entries.append((off, a.nbytes))
         off = (off + a.nbytes + 255) // 256 * 256
     buf = bytearray(off)
-    buf[0:16] = b"MMCW" + struct.pack("<III", 1, 0, n)
+    buf[0:16] = b"MMCW" + struct.pack("<III", 1, A.arch_id, n)
     for i, (o, nb) in enumerate(entries):
         struct.pack_into("<QQ", buf, 16 + 16 * i, o, nb)
     for (o, nb), (_, a) in zip(entries, tensors):
@@ -174,5 +239,5 @@ def pack_backbone(sd: Dict[str, np.ndarray]) -> bytes:
     return bytes(buf)
 
 
-def pack_from_stream(stream) -> bytes:
-    return pack_backbone(load_checkpoint(stream))
+def pack_from_stream(stream, arch=None) -> bytes:
+    return pack_backbone(load_checkpoint(stream, arch), arch)

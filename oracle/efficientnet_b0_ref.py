@@ -86,6 +86,40 @@ STEM_CH = 32
 HEAD_IN = 320
 
 
+class ArchRef(NamedTuple):
+    """One member of the published family: B0's stage table under compound scaling
+    (lukemelas ``round_filters`` / ``round_repeats``: widths to multiples of 8, never below
+    90 % of the scaled value; repeats rounded up)."""
+    name: str
+    stem: int
+    blocks: List[BlockArgs]
+    head_in: int
+    feature_dim: int
+
+
+def _round_filters(c: int, width: float, divisor: int = 8) -> int:
+    c = c * width
+    new = max(divisor, int(c + divisor / 2) // divisor * divisor)
+    if new < 0.9 * c:
+        new += divisor
+    return int(new)
+
+
+def arch_ref(name: str = "b0") -> ArchRef:
+    """``b0`` (the reference path's network) or ``b4`` (width 1.4, depth 1.8; BASELINE.json configs[4],
+    not present in the reference -- same restatement, wider/deeper table)."""
+    width, depth = {"b0": (1.0, 1.0), "b4": (1.4, 1.8)}[name]
+    blocks: List[BlockArgs] = []
+    for rep, k, s, e, cin, cout in _STAGES:
+        cin, cout = _round_filters(cin, width), _round_filters(cout, width)
+        for r in range(int(np.ceil(depth * rep))):
+            blocks.append(BlockArgs(k, s if r == 0 else 1, e, cin if r == 0 else cout, cout))
+    return ArchRef(name, _round_filters(32, width), blocks, blocks[-1].cout, _round_filters(1280, width))
+
+
+assert arch_ref("b0").blocks == B0_BLOCKS
+
+
 def se_channels(cin: int) -> int:
     return max(1, int(cin * 0.25))
 
@@ -101,8 +135,9 @@ def same_pad(size: int, k: int, s: int):
 # Synthetic weights (there is no real efficientnet.pt offline).
 # --------------------------------------------------------------------------
 
-def expected_keys() -> Dict[str, tuple]:
+def expected_keys(arch: str = "b0") -> Dict[str, tuple]:
     """State-dict keys (without the ``module.`` prefix) and shapes of pyspacer's B0."""
+    A = arch_ref(arch)
     keys: Dict[str, tuple] = {}
 
     def bn(prefix: str, c: int):
@@ -112,9 +147,9 @@ def expected_keys() -> Dict[str, tuple]:
         keys[prefix + ".running_var"] = (c,)
         keys[prefix + ".num_batches_tracked"] = ()
 
-    keys["_conv_stem.weight"] = (STEM_CH, 3, 3, 3)
-    bn("_bn0", STEM_CH)
-    for i, b in enumerate(B0_BLOCKS):
+    keys["_conv_stem.weight"] = (A.stem, 3, 3, 3)
+    bn("_bn0", A.stem)
+    for i, b in enumerate(A.blocks):
         p = f"_blocks.{i}."
         ce = b.cin * b.expand
         if b.expand != 1:
@@ -129,9 +164,9 @@ def expected_keys() -> Dict[str, tuple]:
         keys[p + "_se_expand.bias"] = (ce,)
         keys[p + "_project_conv.weight"] = (b.cout, ce, 1, 1)
         bn(p + "_bn2", b.cout)
-    keys["_conv_head.weight"] = (FEATURE_DIM, HEAD_IN, 1, 1)
-    bn("_bn1", FEATURE_DIM)
-    keys["_fc.weight"] = (NUM_FC_CLASSES, FEATURE_DIM)
+    keys["_conv_head.weight"] = (A.feature_dim, A.head_in, 1, 1)
+    bn("_bn1", A.feature_dim)
+    keys["_fc.weight"] = (NUM_FC_CLASSES, A.feature_dim)
     keys["_fc.bias"] = (NUM_FC_CLASSES,)
     return keys
 
@@ -178,7 +213,7 @@ def calibration_patches() -> np.ndarray:
 
 
 def make_synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.ndarray]] = None,
-                              calib_patches: Optional[np.ndarray] = None) -> Dict[str, torch.Tensor]:
+                              calib_patches: Optional[np.ndarray] = None, arch: str = "b0") -> Dict[str, torch.Tensor]:
     """Seeded synthetic B0 weights in the lukemelas/pyspacer key layout.
 
     The random part comes from mermaid_classifier_amd.synthetic (numpy default_rng(seed),
@@ -190,7 +225,7 @@ def make_synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.nda
     the same weights; pass ``bn_stats=None`` to recompute them with ``calib_patches``.
     """
     from mermaid_classifier_amd.synthetic import synthetic_state_dict  # one generator for product and oracle
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_state_dict(seed, bn_stats).items()}
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synthetic_state_dict(seed, bn_stats, arch=arch).items()}
     if bn_stats is not None:
         return sd
     # ---- calibrate BN running stats on data, layer by layer --------------------
@@ -203,7 +238,7 @@ def make_synthetic_state_dict(seed: int = 0, bn_stats: Optional[Dict[str, np.nda
         sd[prefix + ".running_var"] = pre.var(dim=(0, 2, 3), unbiased=False).clone() + 1e-4
 
     with torch.no_grad():
-        _forward(sd, x, calibrate=calib)
+        _forward(sd, x, calibrate=calib, blocks=arch_ref(arch).blocks)
     return sd
 
 
@@ -268,8 +303,8 @@ def _q(x: torch.Tensor, emulate_fp16: bool) -> torch.Tensor:
 
 
 def _forward(sd, x: torch.Tensor, calibrate=None, taps: Optional[dict] = None,
-             emulate_fp16: bool = False) -> torch.Tensor:
-    """extract_features: (B,3,224,224) fp32 -> (B,1280) fp32.
+             emulate_fp16: bool = False, blocks: Optional[List[BlockArgs]] = None) -> torch.Tensor:
+    """extract_features: (B,3,224,224) fp32 -> (B,1280) fp32 (``blocks`` None = B0's table).
 
     ``calibrate(pre_bn_tensor, bn_prefix)`` is the weight generator's hook;
     ``taps`` collects named intermediates (NCHW fp32) for per-kernel parity tests;
@@ -288,7 +323,7 @@ def _forward(sd, x: torch.Tensor, calibrate=None, taps: Optional[dict] = None,
     x = _swish(bn("_bn0", _conv_same(x, sd["_conv_stem.weight"], 2)))
     x = _q(x, emulate_fp16)
     tap("stem", x)
-    for i, b in enumerate(B0_BLOCKS):
+    for i, b in enumerate(B0_BLOCKS if blocks is None else blocks):
         p = f"_blocks.{i}."
         inp = x
         ce = b.cin * b.expand
@@ -319,8 +354,9 @@ def _forward(sd, x: torch.Tensor, calibrate=None, taps: Optional[dict] = None,
 class EfficientNetB0Ref:
     """Oracle net: ``load_weights(stream)`` + ``extract_features(batch)`` like pyspacer's."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor]):
-        want = expected_keys()
+    def __init__(self, state_dict: Dict[str, torch.Tensor], arch: str = "b0"):
+        self.arch = arch_ref(arch)
+        want = expected_keys(arch)
         missing = sorted(set(want) - set(state_dict))
         unexpected = sorted(set(state_dict) - set(want))
         if missing or unexpected:
@@ -337,7 +373,7 @@ class EfficientNetB0Ref:
     @torch.no_grad()
     def extract_features(self, batch: torch.Tensor, taps: Optional[dict] = None,
                          emulate_fp16: bool = False) -> torch.Tensor:
-        return _forward(self.sd, batch.to(torch.float32), taps=taps, emulate_fp16=emulate_fp16)
+        return _forward(self.sd, batch.to(torch.float32), taps=taps, emulate_fp16=emulate_fp16, blocks=self.arch.blocks)
 
 
 def patches_to_features(net: EfficientNetB0Ref, patches_u8: np.ndarray, batch_size: int = 10) -> np.ndarray:
@@ -350,5 +386,5 @@ def patches_to_features(net: EfficientNetB0Ref, patches_u8: np.ndarray, batch_si
         chunk = patches_u8[b * batch_size:(b + 1) * batch_size]
         out.append(net.extract_features(transformation(np.asarray(chunk))).numpy())
     if not out:
-        return np.zeros((0, FEATURE_DIM), dtype=np.float32)
+        return np.zeros((0, net.arch.feature_dim), dtype=np.float32)
     return np.concatenate(out).astype(np.float32)

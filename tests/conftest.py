@@ -25,6 +25,14 @@ def synth_sd():
 
 
 @pytest.fixture(scope="session")
+def synth_sd_b4():
+    """Synthetic EfficientNet-B4 weights (BASELINE.json configs[4]) with their committed BN statistics."""
+    from oracle import efficientnet_b0_ref as bb
+    stats = {k: v.astype(np.float32) for k, v in np.load(GOLDEN / "synth_bn_stats_b4.npz").items()}
+    return bb.make_synthetic_state_dict(seed=0, bn_stats=stats, arch="b4")
+
+
+@pytest.fixture(scope="session")
 def oracle_net(synth_sd):
     from oracle import efficientnet_b0_ref as bb
     import torch

@@ -63,6 +63,24 @@ def backbone():
     print("backbone fixtures written", f_noise.shape, f_nat.shape, f_img.shape)
 
 
+def backbone_b4():
+    """BASELINE.json configs[4]: EfficientNet-B4 (width 1.4, depth 1.8) on 224x224 patches.  Not in the
+    reference: the oracle is the same restatement over the scaled stage table; self-oracle fixtures."""
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = bb.make_synthetic_state_dict(seed=0, bn_stats=None, arch="b4")
+    np.savez_compressed(HERE / "synth_bn_stats_b4.npz", **{k: v.astype(np.float16) for k, v in bb.bn_stats_of(sd).items()})
+    # the committed statistics are fp16-rounded (half the file); rebuild the weights from them so that the
+    # fixture below is computed with exactly what every later run reconstructs
+    stats = {k: v.astype(np.float32) for k, v in np.load(HERE / "synth_bn_stats_b4.npz").items()}
+    sd = bb.make_synthetic_state_dict(seed=0, bn_stats=stats, arch="b4")
+    net = bb.EfficientNetB0Ref(sd, arch="b4")
+    noise = bb.synthetic_patches(4, seed=42)
+    natural = bb.natural_patches(4, seed=7)
+    np.savez_compressed(HERE / "backbone_b4_features.npz", noise4=bb.patches_to_features(net, noise),
+                        natural4=bb.patches_to_features(net, natural))
+    print("b4 fixtures written")
+
+
 def head():
     sys.path.insert(0, "/root/reference")
     sys.path.insert(0, "/root/reference/tests")
@@ -144,5 +162,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["backbone", "head"]
     if "backbone" in which:
         backbone()
+    if "backbone_b4" in which:
+        backbone_b4()
     if "head" in which:
         head()

@@ -15,19 +15,20 @@ import torch.nn.functional as F
 from conftest import GOLDEN, ROOT, rel_l2
 
 
-def _folded_forward(tensors, patches_u8):
+def _folded_forward(tensors, patches_u8, arch="b0"):
     """Evaluate the network from the FOLDED tensors (what the library consumes) in fp32 torch:
     proves fold() + the stem's u8-128 / padval trick reproduce the oracle's arithmetic."""
-    from mermaid_classifier_amd.weights import B0_BLOCKS
+    from mermaid_classifier_amd.weights import get_arch
+    A = get_arch(arch)
     t = {k: torch.from_numpy(v) for k, v in tensors}
     u = torch.from_numpy(patches_u8.astype(np.float32) - 128.0).permute(0, 3, 1, 2)   # (B,3,224,224)
     pv = t["stem.padval"].view(1, 3, 1, 1)
     up = pv.expand(u.shape[0], 3, 225, 225).clone()
     up[:, :, :224, :224] = u                                                          # pad right/bottom with padval
-    w = t["stem.weight"].view(32, 3, 3, 3).permute(0, 3, 1, 2)                        # (n,ky,kx,c)->(n,c,ky,kx)
+    w = t["stem.weight"].view(A.stem, 3, 3, 3).permute(0, 3, 1, 2)                    # (n,ky,kx,c)->(n,c,ky,kx)
     x = F.conv2d(up, w, t["stem.bias"], stride=2)
     x = x * torch.sigmoid(x)
-    for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
+    for i, (k, s, e, cin, cout) in enumerate(A.blocks):
         inp = x
         ce = cin * e
         if e != 1:
@@ -47,7 +48,7 @@ def _folded_forward(tensors, patches_u8):
         x = F.conv2d(x, t[f"b{i}.project.weight"].view(cout, ce, 1, 1), t[f"b{i}.project.bias"])
         if s == 1 and cin == cout:
             x = x + inp
-    x = F.conv2d(x, t["head.weight"].view(1280, 320, 1, 1), t["head.bias"])
+    x = F.conv2d(x, t["head.weight"].view(A.feature_dim, A.head_in, 1, 1), t["head.bias"])
     x = x * torch.sigmoid(x)
     return x.mean(dim=(2, 3)).numpy()
 
@@ -62,6 +63,29 @@ def test_fold_reproduces_oracle(synth_sd, oracle_net):
         got = _folded_forward(tensors, patches)
         want = oracle_net.extract_features(ref.transformation(patches)).numpy()
     assert rel_l2(got, want).max() < 2e-5
+
+
+def test_b4_arch_table_fold_and_blob(synth_sd_b4):
+    """BASELINE.json configs[4]: the compound-scaled table (product and oracle derive it independently), its folding, and
+    the blob header's arch id."""
+    from mermaid_classifier_amd import weights
+    from oracle import efficientnet_b0_ref as ref
+    A = weights.get_arch("b4")
+    R = ref.arch_ref("b4")
+    assert (A.stem, A.head_in, A.feature_dim, len(A.blocks)) == (48, 448, 1792, 32) == (R.stem, R.head_in, R.feature_dim, len(R.blocks))
+    assert [tuple(b) for b in R.blocks] == A.blocks
+    assert weights.detect_arch(synth_sd_b4) is A
+    sd = {k: np.asarray(v.numpy(), np.float64) for k, v in synth_sd_b4.items() if k in weights.expected_shapes(A)}
+    tensors = weights.fold(sd, A)
+    patches = ref.natural_patches(1, seed=7)
+    with torch.no_grad():
+        got = _folded_forward(tensors, patches, "b4")
+        want = ref.EfficientNetB0Ref(synth_sd_b4, arch="b4").extract_features(ref.transformation(patches)).numpy()
+    assert rel_l2(got, want).max() < 2e-5
+    blob = weights.pack_backbone(sd, A)
+    assert struct.unpack_from("<III", blob, 4) == (1, 1, len(tensors))
+    with pytest.raises(ValueError):
+        weights.get_arch("b7")
 
 
 def test_blob_layout_roundtrip(synth_sd):
