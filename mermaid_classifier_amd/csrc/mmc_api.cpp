@@ -1020,33 +1020,41 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
     return 0;
 }
 
-// One pass over n <= max_batch resident patches: split into lanes, fork from / join to the caller's stream.
+// One pass over n resident patches: split into lanes, fork from / join to the caller's stream ONCE.  n may exceed
+// max_batch: the pass is then a sequence of max_batch-sized chunks, and each lane walks its sub-batch of every chunk on its
+// own stream without waiting for the other lanes -- the drain of one chunk (the last lane's per-patch kernels, which fill
+// half the chip) overlaps the first kernels of the next chunk.  Sub-batch shapes are those of separate calls, so results are
+// bitwise the same.
 static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, float* out_dev, hipStream_t st, Prof* prof)
 {
     // Profiling records HIP events on each lane's own stream, i.e. durations as they are with the lanes running
     // concurrently (what rocprofv3 sees); MMC_PROFILE_SERIAL=1 profiles one lane at a time instead (isolated kernels).
     static const bool serial_prof = [] { const char* e = getenv("MMC_PROFILE_SERIAL"); return e && e[0] == '1'; }();
-    if (bb->nlanes == 1 || (prof && serial_prof) || n < 2 * bb->nlanes)
-        return (n <= bb->lane_cap) ? forward_lane(bb, bb->lanes[0], patches_dev, n, out_dev, st, prof)
-                                   : [&]() {
-                                         for (int off = 0; off < n; off += bb->lane_cap) {
-                                             const int cur = n - off < bb->lane_cap ? n - off : bb->lane_cap;
-                                             int r = forward_lane(bb, bb->lanes[0], patches_dev + (size_t)off * IMG * IMG * 3, cur,
-                                                                  out_dev + (size_t)off * bb->feat, st, prof);
-                                             if (r) return r;
-                                         }
-                                         return 0;
-                                     }();
+    const size_t psz = (size_t)IMG * IMG * 3, FEAT = (size_t)bb->feat;
+    if (bb->nlanes == 1 || (prof && serial_prof) || n < 2 * bb->nlanes) {
+        for (int off = 0; off < n; off += bb->lane_cap) {
+            const int cur = n - off < bb->lane_cap ? n - off : bb->lane_cap;
+            int r = forward_lane(bb, bb->lanes[0], patches_dev + (size_t)off * psz, cur, out_dev + (size_t)off * FEAT, st, prof);
+            if (r) return r;
+        }
+        return 0;
+    }
     HIP_TRY(hipEventRecord(bb->fork, st));
-    const int per = (n + bb->nlanes - 1) / bb->nlanes;
+    for (int l = 0; l < bb->nlanes; ++l) HIP_TRY(hipStreamWaitEvent(bb->lanes[l].stream, bb->fork, 0));
+    for (int base = 0; base < n; base += bb->max_batch) {          // chunk-major enqueue: the lanes' launches interleave on the host
+        const int cn = n - base < bb->max_batch ? n - base : bb->max_batch;
+        const int per = (cn + bb->nlanes - 1) / bb->nlanes;
+        for (int l = 0; l < bb->nlanes; ++l) {
+            const int off = l * per;
+            const int cur = cn - off < per ? cn - off : per;
+            if (cur <= 0) break;
+            mmc_backbone::Lane& L = bb->lanes[l];
+            int r = forward_lane(bb, L, patches_dev + (size_t)(base + off) * psz, cur, out_dev + (size_t)(base + off) * FEAT, L.stream, prof);
+            if (r) return r;
+        }
+    }
     for (int l = 0; l < bb->nlanes; ++l) {
-        const int off = l * per;
-        const int cur = n - off < per ? n - off : per;
-        if (cur <= 0) break;
         mmc_backbone::Lane& L = bb->lanes[l];
-        HIP_TRY(hipStreamWaitEvent(L.stream, bb->fork, 0));
-        int r = forward_lane(bb, L, patches_dev + (size_t)off * IMG * IMG * 3, cur, out_dev + (size_t)off * bb->feat, L.stream, prof);
-        if (r) return r;
         HIP_TRY(hipEventRecord(L.done, L.stream));
         HIP_TRY(hipStreamWaitEvent(st, L.done, 0));
     }
@@ -1056,7 +1064,7 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
 // forward_pass through a cached HIP graph (device-resident buffers only); falls back to plain launches on any error
 static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hipStream_t st)
 {
-    if (!bb->use_graph) return forward_pass(bb, pin, n, pout, st, nullptr);
+    if (!bb->use_graph || n > 8 * bb->max_batch) return forward_pass(bb, pin, n, pout, st, nullptr);   // (bounded graph size)
     for (auto& g : bb->graphs)
         if (g.in == pin && g.out == pout && g.n == n) {
             HIP_TRY(hipGraphLaunch(g.exec, st));
@@ -1104,6 +1112,15 @@ extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64
     HIP_TRY(hipSetDevice(bb->device));
     const size_t psz = (size_t)IMG * IMG * 3;
     const uint8_t* in = static_cast<const uint8_t*>(patches);
+    if (!(flags & (MMC_IN_HOST | MMC_OUT_HOST)) && !bb->keep) {
+        // device-resident buffers: the whole call is one pass (pipelined over max_batch-sized chunks when n is larger)
+        for (int64_t off = 0; off < n; off += (1 << 20)) {
+            const int cur = (int)((n - off) < (1 << 20) ? (n - off) : (1 << 20));
+            int r = run_pass(bb, in + (size_t)off * psz, cur, out_features + (size_t)off * bb->feat, st);
+            if (r) return r;
+        }
+        return MMC_OK;
+    }
     for (int64_t off = 0; off < n; off += bb->max_batch) {
         const int cur = (int)((n - off) < bb->max_batch ? (n - off) : bb->max_batch);
         const uint8_t* pin = in + (size_t)off * psz;

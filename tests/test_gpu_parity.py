@@ -102,6 +102,25 @@ def test_device_resident_path_matches_host_path(backbone):
     assert np.array_equal(host, dev.cpu().numpy())
 
 
+def test_pipelined_multi_chunk_call_is_bitwise_the_chunks(backbone):
+    """A device-resident call with n > max_batch is ONE pass pipelined over max_batch-sized chunks (each lane walks its
+    sub-batches without waiting for the others; one fork/join): bits equal those of separate per-chunk calls, plain
+    launches and graph replay alike (the third identical call replays the captured graph)."""
+    import torch
+    from oracle import efficientnet_b0_ref as ref
+    p = torch.from_numpy(ref.natural_patches(53, seed=21)).cuda()     # max_batch 16: chunks 16,16,16,5 (ragged, odd)
+    out = torch.empty((53, 1280), dtype=torch.float32, device="cuda")
+    runs = []
+    for _ in range(4):
+        out.zero_()
+        backbone.extract(p, out=out)
+        torch.cuda.synchronize()
+        runs.append(out.cpu().numpy().copy())
+    parts = np.concatenate([backbone.extract(p[i:i + 16]).cpu().numpy() for i in range(0, 53, 16)])
+    for r in runs:
+        assert np.array_equal(r, parts)
+
+
 def test_extractor_contract_and_image_path(checkpoint_path, oracle_net, golden_backbone):
     """The reference's two call shapes: patches_to_features(list[PIL]) and extractor(image, rowcols)."""
     from PIL import Image
