@@ -122,6 +122,33 @@ int mmc_head_num_classes(const mmc_head* h);
 int mmc_head_predict(mmc_head* h, const float* feats, int64_t n, float* proba, int32_t* argmax,
                      unsigned flags, void* hip_stream);
 
+/* ---- MLP classifier training on precomputed feature vectors --------------------------------
+ * Replaces: the arithmetic of TorchMLPClassifier.partial_fit (mermaid_classifier/pyspacer/torch_classifier.py:226-303)
+ *   as driven by the trainer's batch loop (mermaid_classifier/pyspacer/trainer.py:138-145): per mini-batch
+ *   logits -> F.cross_entropy(weight=class_weight) + (0.5*alpha/mb)*sum(W^2) -> backward -> torch.optim.Adam.step().
+ * The host side keeps what the reference keeps on the host: classes_/label lookup, Glorot initialisation (torch RNG, so
+ * the same random_state gives the same initial weights), the shuffle order, loss_curve_/n_iter_ bookkeeping.
+ * W[l]: (dims[l+1], dims[l]) row-major fp32, b[l]: (dims[l+1]) -- the initial parameters (host pointers);
+ * class_weight: K floats in classes_ order or NULL; Adam moments start at zero, step count at 0. */
+typedef struct mmc_trainer mmc_trainer;
+int mmc_trainer_create(const float* const* W, const float* const* b, const int* dims, int n_layers, float lr, float beta1,
+                       float beta2, float eps, float alpha, const float* class_weight, int device, mmc_trainer** out);
+void mmc_trainer_destroy(mmc_trainer* t);
+/* One pass over n samples ALREADY IN VISITING ORDER (the caller applies the shuffle, torch_classifier.py:251-257):
+ * X n x dims[0] fp32 and y n int32 class indices, host pointers; mini-batches of `batch_size` rows (last one ragged),
+ * one Adam step each.  *avg_loss = sum(loss_i * mb_i) / n, the value the reference appends to loss_curve_ (:293-300).
+ * Synchronises `hip_stream` before returning. */
+int mmc_trainer_partial_fit(mmc_trainer* t, const float* X, const int32_t* y, int64_t n, int batch_size, double* avg_loss,
+                            void* hip_stream);
+/* Current parameters to host buffers shaped like the create-time ones. */
+int mmc_trainer_get_params(mmc_trainer* t, float* const* W, float* const* b);
+/* Adam moments (which = 0: exp_avg, 1: exp_avg_sq) and step count, read (set = 0) or written (set = 1): what the
+ * reference pickles as the optimizer state dict (torch_classifier.py:404-415). */
+int mmc_trainer_adam_state(mmc_trainer* t, int which, int set, float* const* W, float* const* b, long long* step);
+/* Raw logits of the current parameters: X n x dims[0] host -> logits n x K host (the softmax / float64 renormalisation of
+ * _forward_probs, torch_classifier.py:332-376, stays on the host). */
+int mmc_trainer_logits(mmc_trainer* t, const float* X, int64_t n, float* logits, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

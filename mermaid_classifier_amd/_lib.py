@@ -22,6 +22,8 @@ SYMBOLS = [
     "mmc_backbone_workspace_bytes", "mmc_backbone_extract", "mmc_backbone_read_activation",
     "mmc_backbone_profile", "mmc_crop_patches",
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
+    "mmc_trainer_create", "mmc_trainer_destroy", "mmc_trainer_partial_fit", "mmc_trainer_get_params", "mmc_trainer_adam_state",
+    "mmc_trainer_logits",
 ]
 
 
@@ -80,6 +82,19 @@ def _load() -> C.CDLL:
     lib.mmc_head_num_classes.argtypes = [vp]
     lib.mmc_head_predict.restype = i32
     lib.mmc_head_predict.argtypes = [vp, vp, i64, vp, vp, u32, vp]
+    f32 = C.c_float
+    lib.mmc_trainer_create.restype = i32
+    lib.mmc_trainer_create.argtypes = [C.POINTER(fp), C.POINTER(fp), C.POINTER(i32), i32, f32, f32, f32, f32, f32, fp, i32, C.POINTER(vp)]
+    lib.mmc_trainer_destroy.restype = None
+    lib.mmc_trainer_destroy.argtypes = [vp]
+    lib.mmc_trainer_partial_fit.restype = i32
+    lib.mmc_trainer_partial_fit.argtypes = [vp, vp, vp, i64, i32, C.POINTER(C.c_double), vp]
+    lib.mmc_trainer_get_params.restype = i32
+    lib.mmc_trainer_get_params.argtypes = [vp, C.POINTER(fp), C.POINTER(fp)]
+    lib.mmc_trainer_adam_state.restype = i32
+    lib.mmc_trainer_adam_state.argtypes = [vp, i32, i32, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_longlong)]
+    lib.mmc_trainer_logits.restype = i32
+    lib.mmc_trainer_logits.argtypes = [vp, vp, i64, vp, vp]
     return lib
 
 

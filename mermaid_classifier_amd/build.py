@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OUT = HERE / "libmermaid_mi355.so"
-SOURCES = ["kernels.hip", "mmc_api.cpp"]
+SOURCES = ["kernels.hip", "trainer.hip", "mmc_api.cpp"]
 DEPS = SOURCES + ["kernels.h", "../../include/mmc.h"]
 
 

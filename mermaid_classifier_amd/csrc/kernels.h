@@ -5,6 +5,9 @@
 
 enum { EPI_SILU = 0, EPI_LINEAR = 1, EPI_GAP = 2 };
 
+// sets the thread-local message mmc_last_error() returns and hands back `code` (defined in mmc_api.cpp)
+int mmc_fail(int code, const char* fmt, ...);
+
 struct GemmArgs {
     const _Float16* X;   // [M][K] activations (NHWC rows)
     int M, K;

@@ -38,6 +38,16 @@ static int fail(int code, const char* fmt, ...)
                                  r_ > 0 ? hipGetErrorString((hipError_t)r_) : "unsupported shape"); \
     } while (0)
 
+// error plumbing for the other translation units (trainer.hip)
+int mmc_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 extern "C" const char* mmc_last_error(void) { return g_err; }
 extern "C" int mmc_version(void) { return 1; }
 extern "C" int mmc_device_count(void)

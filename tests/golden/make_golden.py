@@ -158,6 +158,38 @@ def head():
     print("head108 held-out accuracy", acc)
 
 
+def trainer():
+    """the reference's own TorchMLPClassifier (imported from /root/reference) trained for three
+    partial_fit passes on a seeded dataset -- inputs, initial and final parameters, loss curve, probabilities."""
+    sys.path.insert(0, "/root/reference")
+    from mermaid_classifier.pyspacer.torch_classifier import TorchMLPClassifier, _MLPModule  # type: ignore
+    rng = np.random.default_rng(5)
+    k, nf, n = 7, 64, 730                      # 730 = 3 x 200 + a ragged mini-batch of 130
+    classes = np.array([f"c{i}" for i in range(k)])
+    centers = rng.normal(0, 1.0, size=(k, nf)).astype(np.float32)
+    yi = rng.integers(0, k, size=n)
+    X = (centers[yi] + rng.normal(0, 1.5, size=(n, nf))).astype(np.float32)
+    y = classes[yi]
+    cw = {c: float(w) for c, w in zip(classes, [1.0, 0.5, 2.0, 1.0, 0.0, 3.0, 1.5])}
+    out = {"X": X, "y_idx": yi.astype(np.int64), "classes": classes, "class_weight": np.array([cw[c] for c in classes], np.float32)}
+    for tag, weight in (("plain", None), ("weighted", cw)):
+        torch.manual_seed(0)
+        init = _MLPModule(nf, (48, 32), k)
+        clf = TorchMLPClassifier(hidden_layer_sizes=(48, 32), learning_rate_init=1e-3, alpha=1e-3, random_state=0, class_weight=weight)
+        for _ in range(3):
+            clf.partial_fit(X, y, classes=classes.tolist())
+        for i, (m0, m1) in enumerate(zip(init.linears, clf._module.linears)):
+            if tag == "plain":
+                out[f"W{i}_init"] = m0.weight.detach().numpy().copy()
+                out[f"b{i}_init"] = m0.bias.detach().numpy().copy()
+            out[f"W{i}_{tag}"] = m1.weight.detach().numpy().copy()
+            out[f"b{i}_{tag}"] = m1.bias.detach().numpy().copy()
+        out[f"loss_curve_{tag}"] = np.array(clf.loss_curve_, dtype=np.float64)
+        out[f"proba_{tag}"] = clf.predict_proba(X[:64])
+        print("trainer", tag, "loss curve", clf.loss_curve_, "acc", (clf.predict(X) == y).mean())
+    np.savez_compressed(HERE / "trainer_fixture.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["backbone", "head"]
     if "backbone" in which:
@@ -166,3 +198,5 @@ if __name__ == "__main__":
         backbone_b4()
     if "head" in which:
         head()
+    if "trainer" in which:
+        trainer()
