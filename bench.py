@@ -119,27 +119,62 @@ def main():
 
     from mermaid_classifier_amd.dist import gather_features
 
+    # N > 1: one RCCL all-gather per step, by default on the same stream right after the extract.  MMC_BENCH_OVERLAP=1 (opt-in,
+    # unmeasured on > 1 GPU: at world size 1 it costs 2 %) issues it asynchronously on RCCL's own stream while the next step's
+    # kernels run: feature / gathered buffers are double-buffered, a buffer is reused only after the all-gather that read it
+    # has been waited for, and every outstanding collective is waited for before the clock stops.
+    use_dist = world > 1 or os.environ.get("MMC_BENCH_FORCE_DIST") == "1"
+    if use_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    overlap = use_dist and os.environ.get("MMC_BENCH_OVERLAP", "0") == "1"
+    fbuf = [feats, torch.empty_like(feats)] if overlap else [feats]
+    gbuf = [torch.empty((world * BATCH, 1280), dtype=torch.float32, device=dev) for _ in fbuf] if overlap else []
+    pending = [None, None]
+    counter = [0]
+
     def step():
-        bb.extract(patches, out=feats)
-        if world > 1:
-            gather_features(feats, world * BATCH)   # one RCCL all-gather of the (BATCH,1280) blocks
+        if not overlap:
+            bb.extract(patches, out=feats)
+            if use_dist:
+                gather_features(feats, world * BATCH)   # one RCCL all-gather of the (BATCH,1280) blocks
+            return
+        i = counter[0] & 1
+        counter[0] += 1
+        if pending[i] is not None:
+            pending[i].wait()          # the collective that read fbuf[i] / wrote gbuf[i] two steps ago (stream-level wait)
+        bb.extract(patches, out=fbuf[i])
+        pending[i] = dist.all_gather_into_tensor(gbuf[i], fbuf[i], async_op=True)
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    drain()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    drain()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if overlap:
+        feats = fbuf[(counter[0] - 1) & 1]
+        if not torch.equal(gbuf[(counter[0] - 1) & 1][rank * BATCH:(rank + 1) * BATCH], feats):
+            raise SystemExit("gathered feature block differs from the local features")
     if not np.isfinite(feats.float().sum().item()):
         raise SystemExit("non-finite features")
 
@@ -194,7 +229,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "EfficientNet-B0 forward, batch=256 random 224x224 u8 patches per GPU -> (256,1280) fp32"
-                                   + ("; RCCL all-gather of features" if world > 1 else ""),
+                                   + ("; RCCL all-gather of features" + (" overlapped with the next step" if overlap else "") if world > 1 else ""),
                        "per_gpu_batch": BATCH, "global_batch": world * BATCH, "weights": "synthetic seed 0",
                        "lanes_per_gpu": bb.lanes,
                        "parallelism": f"patch-sharded x{world}"},
@@ -205,7 +240,7 @@ def main():
         kernels = sorted(((k, v[0] / args.profile_passes) for k, v in per_kernel.items()), key=lambda kv: -kv[1])
         print("# per-kernel ms/step (HIP events): " + ", ".join(f"{k}={v:.3f}" for k, v in kernels), file=sys.stderr)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
