@@ -170,7 +170,7 @@ int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, co
 int launch_se_small(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
                     const float* we, const float* be, float* gate, hipStream_t st);
 int launch_se_wide(const float* pool_part, int nparts, int B, int C, int Cs, const float* wr, const float* br,
-                   const float* we, const float* be, float* gate, hipStream_t st);
+                   const float* we_t /* [Cs][C] */, const float* be, float* gate, hipStream_t st);
 int launch_mlp_layer(const float* X, int M, int K, const float* W, const float* bias, float* Y, int N, bool relu,
                      hipStream_t st);
 int launch_calibrate(const float* logits, int M, int K, const float* a, const float* b, float* proba, int32_t* argmax,

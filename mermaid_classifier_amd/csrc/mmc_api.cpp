@@ -526,7 +526,14 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 std::vector<float> wrn((size_t)B.cs * B.ce);
                 for (size_t e = 0; e < wrn.size(); ++e) wrn[e] = (float)(wr[e] * psc);
                 TRY_OR_FREE(dev_upload(bb, &B.se_wr_nat, wrn));
-                TRY_OR_FREE(dev_upload(bb, &B.se_we_nat, std::vector<float>(we, we + (size_t)B.ce * B.cs)));
+                if (is_b0) {
+                    TRY_OR_FREE(dev_upload(bb, &B.se_we_nat, std::vector<float>(we, we + (size_t)B.ce * B.cs)));
+                } else {   // se_wide_kernel reads the excite FC transposed ([Cs][C]): neighbouring lanes, neighbouring words
+                    std::vector<float> wet((size_t)B.cs * B.ce);
+                    for (int c = 0; c < B.ce; ++c)
+                        for (int j = 0; j < B.cs; ++j) wet[(size_t)j * B.ce + c] = we[(size_t)c * B.cs + j];
+                    TRY_OR_FREE(dev_upload(bb, &B.se_we_nat, wet));
+                }
                 TRY_OR_FREE(dev_upload(bb, &B.se_br_nat, std::vector<float>(br, br + B.cs)));
             }
             TRY_OR_FREE(dev_upload(bb, &B.se_wrp, wrp));
