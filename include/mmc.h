@@ -103,7 +103,11 @@ int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, f
  *   (reached from scripts/build_feature_bucket.py:775 and
  *    mermaid_classifier/pyspacer/annotation.py:241): reflect-pad by 224, slice 224x224 around
  *   each (row,col).  Implemented as index arithmetic on the resident image (no padded copy).
- * image: H x W x 3 u8; rowcols: n x 2 int32 (row, col); patches_out: n x 224 x 224 x 3 u8 (device). */
+ * image: H x W x 3 u8; rowcols: n x 2 int32 (row, col); patches_out: n x 224 x 224 x 3 u8 (device).
+ * With MMC_IN_HOST and few points on a big image (n * 150528 * 6 <= image bytes -- the reference's data: 10-25 points on a
+ * 27 MP image) the patches are cut on the host (same index arithmetic, up to 4 threads, into a pinned ring slot) and only
+ * they are uploaded; otherwise the image is uploaded and crop_kernel cuts them.  Same bytes either way.  The host image is
+ * fully consumed before the call returns; the upload is asynchronous on `hip_stream`.  Env MMC_CROP_HOST=0/1 forces a path. */
 int mmc_crop_patches(const void* image, int height, int width, const int32_t* rowcols, int64_t n,
                      void* patches_out_dev, unsigned flags, int device, void* hip_stream);
 

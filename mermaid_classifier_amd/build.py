@@ -33,7 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         raise RuntimeError("hipcc not found: cannot build libmermaid_mi355.so")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results land in VGPRs: no v_accvgpr_read per element
-           "-Wno-unused-result", "-Wno-unused-value", "-o", str(OUT)] + SOURCES
+           "-Wno-unused-result", "-Wno-unused-value", "-pthread", "-o", str(OUT)] + SOURCES
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=str(CSRC), check=True)

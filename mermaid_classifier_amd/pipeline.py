@@ -41,14 +41,21 @@ class BatchedExtractor:
         self.bb = backbone
         self.cap = int(batch_patches)
         self.dev = torch.device("cuda", backbone.device_index)
-        self._buf = torch.empty((self.cap, PATCH, PATCH, 3), dtype=torch.uint8, device=self.dev)
+        # two patch buffers: while the backbone works through one, the next images are cut / uploaded into the other on a
+        # separate copy stream (a buffer is refilled only after the pass that read it has finished: per-buffer event)
+        self._bufs = [torch.empty((self.cap, PATCH, PATCH, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self._free = [torch.cuda.Event(), torch.cuda.Event()]
+        self._done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._host = [torch.empty((self.cap, backbone.feature_dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._copy_stream = torch.cuda.Stream(device=self.dev)
+        self._buf = self._bufs[0]
 
     def _crop_into(self, image: np.ndarray, rowcols: np.ndarray, offset: int) -> None:
         n = rowcols.shape[0]
         dst = self._buf[offset:offset + n]
         _lib.check(_lib.lib().mmc_crop_patches(image.ctypes.data, image.shape[0], image.shape[1], rowcols.ctypes.data, n,
                                                dst.data_ptr(), _lib.MMC_IN_HOST, self.bb.device_index,
-                                               _current_stream_ptr(self.bb.device_index)))
+                                               int(self._copy_stream.cuda_stream)))
 
     def extract_images(self, images: Iterable[np.ndarray], rowcols_per_image: Iterable[Sequence[Tuple[int, int]]]) -> List[np.ndarray]:
         """-> one (n_points, 1280) float32 array per image (empty arrays for images without points)."""
@@ -56,16 +63,37 @@ class BatchedExtractor:
         out: List[Optional[np.ndarray]] = []
         pending: List[Tuple[int, int, int]] = []   # (image index, offset in buffer, n)
         fill = 0
+        cur = 0                                     # buffer being filled
+        in_flight = None                            # (device features, pending list) of the pass launched last
+        compute = torch.cuda.current_stream(self.dev)
+        self._buf = self._bufs[cur]
+        self._copy_stream.wait_stream(compute)      # whatever wrote these buffers before is done before the first cut lands
 
-        def flush():
-            nonlocal fill, pending
-            if fill == 0:
-                return
-            feats = self.bb.extract(self._buf[:fill]).cpu().numpy()
-            for idx, off, n in pending:
+        def collect(job):
+            slot, count, items = job
+            self._done[slot].synchronize()                       # this pass's D2H only -- not whatever was enqueued after it
+            feats = self._host[slot][:count].numpy().copy()
+            for idx, off, n in items:
                 part = feats[off:off + n]
                 out[idx] = part if out[idx] is None else np.concatenate([out[idx], part])
+
+        def flush():
+            nonlocal fill, pending, cur, in_flight
+            if fill == 0:
+                return
+            compute.wait_stream(self._copy_stream)              # the cuts of this buffer have landed
+            feats_dev = self.bb.extract(self._bufs[cur][:fill])  # asynchronous on the compute stream
+            self._free[cur].record(compute)
+            self._host[cur][:fill].copy_(feats_dev, non_blocking=True)   # pinned: the D2H is stream-ordered too
+            self._done[cur].record(compute)
+            job = (cur, fill, pending)
+            if in_flight is not None:
+                collect(in_flight)                               # the previous pass; this one keeps running meanwhile
+            in_flight = job
             fill, pending = 0, []
+            cur ^= 1
+            self._buf = self._bufs[cur]
+            self._copy_stream.wait_event(self._free[cur])        # refill only after the pass that read this buffer
 
         for idx, (image, rowcols) in enumerate(zip(images, rowcols_per_image)):
             im = np.asarray(image)
@@ -89,6 +117,8 @@ class BatchedExtractor:
                 fill += take
                 start += take
         flush()
+        if in_flight is not None:
+            collect(in_flight)
         return [o if o is not None else np.zeros((0, self.bb.feature_dim), np.float32) for o in out]
 
     def extract_image_features(self, images, rowcols_per_image) -> List[ImageFeatures]:

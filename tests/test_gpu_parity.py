@@ -161,6 +161,24 @@ def test_crop_kernel_matches_oracle_bitwise():
     assert np.array_equal(got, want)
 
 
+def test_sparse_points_are_cut_on_the_host_bitwise():
+    """Few points on a big host image (the reference's data: 10-25 points per 27 MP image) are cut on the host into a pinned
+    ring slot and only the patches are uploaded; same bits as the oracle, borders included, ring reuse included."""
+    import torch
+    from mermaid_classifier_amd.backbone import crop_patches_device
+    from oracle import pyspacer_ref
+    rng = np.random.default_rng(6)
+    image = rng.integers(0, 256, (1300, 1500, 3), dtype=np.uint8)          # 5.85 MB: up to 6 points take the host path
+    sets = [[(0, 0), (1299, 1499), (0, 1499), (1299, 0), (650, 700)], [(111, 112), (113, 1387), (1188, 5)], [(640, 1388)],
+            [(5, 5), (1294, 1494)], [(700, 111), (700, 112), (112, 700), (111, 700)], [(1187, 1387)]]
+    outs = [crop_patches_device(image, rc) for rc in sets]                  # 6 calls: wraps the 4-slot ring
+    torch.cuda.synchronize()
+    for rc, got in zip(sets, outs):
+        assert np.array_equal(got.cpu().numpy(), pyspacer_ref.crop_patches(image, rc, 224))
+    dense = [(int(r), int(c)) for r, c in zip(rng.integers(0, 1300, 40), rng.integers(0, 1500, 40))]   # crop_kernel path
+    assert np.array_equal(crop_patches_device(image, dense).cpu().numpy(), pyspacer_ref.crop_patches(image, dense, 224))
+
+
 @pytest.mark.parametrize("name", ["head_fixture", "head108"])
 def test_head_matches_reference_predictor(name):
     """HIP head vs outputs of the reference's own CalibratedHead/Predictor (golden, generated by
