@@ -27,7 +27,7 @@ extern "C" {
 
 #define MMC_ARCH_B0 0   /* efficientnet-b0: the network pyspacer's EfficientNetExtractor builds (the reference path) */
 #define MMC_ARCH_B4 1   /* efficientnet-b4 (width 1.4, depth 1.8) on 224x224 patches: BASELINE.json configs[4]; not in the
-                         * reference; runs on the generic per-layer kernels (no fused schedule yet), feature_dim 1792 */
+                         * reference; fused expand+depthwise kernels plus the shape-generic squeeze-excite / project / head kernels, feature_dim 1792 */
 
 /* memory-kind flags for mmc_backbone_extract / mmc_head_predict / mmc_crop_patches */
 #define MMC_IN_DEVICE 0u

@@ -182,6 +182,23 @@ static const FuseCfg B0_FUSE[16] = {
     {14, 14, 48, 2, 1, 0},  {7, 7, 48, 1, 1, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},
     {7, 7, 96, 1, 2, 0}};
 
+// The same choices by layer geometry for the other members of the family (B4): the tile and chunk B0 uses at that
+// resolution / stride / kernel size, with CC a divisor of the expanded width.
+static FuseCfg generic_fuse_cfg(int H, int k, int s, int ce)
+{
+    FuseCfg fc{0, 0, 0, 0, 1, 0};
+    if (H == 112 && s == 2) fc = {8, 8, 48, 2, 1, 0};
+    else if (H == 56 && s == 1) fc = {14, 14, 48, 2, 1, 0};
+    else if (H == 56 && s == 2) fc = {4, 14, 48, 2, 1, 0};
+    else if (H == 28 && s == 1) fc = {14, 14, 48, 2, 1, 0};
+    else if (H == 28 && s == 2) fc = {2, 14, 48, 2, 1, 0};
+    else if (H == 14 && s == 1) fc = {14, 14, k == 3 ? 96 : 48, 2, 1, 0};
+    else if (H == 14 && s == 2) fc = {7, 7, 48, 1, 1, 0};
+    else if (H == 7 && s == 1) fc = {7, 7, 96, 1, 2, 0};
+    if (fc.CC && ce % fc.CC) fc.TH = 0;
+    return fc;
+}
+
 struct Saved {
     void* dev = nullptr;
     size_t bytes = 0;
@@ -415,6 +432,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const bool fuse_enabled = is_b0 && !(fuse_env && fuse_env[0] == '0');   // the fused kernels are shaped for B0's layers
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
+    const bool fuse_generic = !is_b0 && !(fuse_env && fuse_env[0] == '0');   // B4: fused expand+depthwise where an instantiation fits
     bb->fuse_stem = fuse_enabled;
     const char* pp_env = getenv("MMC_PROJSE");
     const bool projse_enabled = fuse_enabled && !(pp_env && pp_env[0] == '0');
@@ -602,8 +620,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         const int passes = (strips + B.S - 1) / B.S;
         B.iters = passes >= 8 ? 4 : 1;
         B.parts = (passes + B.iters - 1) / B.iters;
-        if (B.has_expand && fuse_enabled && i < 16) {
-            FuseCfg fc = B0_FUSE[i];
+        if (B.has_expand && ((fuse_enabled && i < 16) || fuse_generic)) {
+            FuseCfg fc = is_b0 ? B0_FUSE[i] : generic_fuse_cfg(H, B.d.k, B.d.s, B.ce);
             if (const char* ov = getenv("MMC_FUSE_CFG")) {   // "i:TH,TWo,CC;..." experiment override
                 char key[16];
                 snprintf(key, sizeof key, "%d:", i);
@@ -655,7 +673,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     B.fused = true;
                     // dot2 depthwise variant: only where it measured faster (5x5 stride-1 blocks; MI355X, batch 128/256)
                     static const bool B0_DOT2[16] = {0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 1, 1, 1, 0};
-                    if (dot2_enabled && (B0_DOT2[i] || (dot2_env && dot2_env[0] == '2'))) {
+                    if (is_b0 && dot2_enabled && (B0_DOT2[i] || (dot2_env && dot2_env[0] == '2'))) {
                         // window of mbconv_d_kernel: rows as above, columns widened to whole pixel pairs (even absolute x)
                         const int padb = B.pad;
                         int rowlen = 0;
