@@ -154,6 +154,8 @@ struct ProjPatchArgs {
     float psc;                // 1 / (HW * log2 e)
 };
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st);
+int proj_patch_ksteps(int K);                        // k-steps (of 32) its weight image must be packed with
+int proj_patch_has(int K, int N, int HW, int res);   // 1 when launch_proj_patch has an instantiation for this layer shape
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);
 // block 1 reading block 0's depthwise output, with block 0's SE scale + project conv folded in

@@ -2637,7 +2637,7 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
 template <int KS, int NF, int HW, bool RES>
 __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 {
-    constexpr int CK = (KS <= 8) ? KS : (KS % 7 == 0 ? 7 : 5);   // k-steps per chunk (KS = 21 -> 7, 15 -> 5)
+    constexpr int CK = (KS <= 8) ? KS : (KS % 7 == 0 ? 7 : (KS % 5 == 0 ? 5 : 6));   // k-steps per chunk (KS = 21 -> 7, 15 -> 5, 12 -> 6)
     constexpr int NCH = KS / CK;
     static_assert(KS % CK == 0, "chunking");
     constexpr int NPF = (HW + 15) / 16, NPAIR = (NPF + 1) / 2;
@@ -3415,6 +3415,13 @@ int launch_tail7(const TailArgs& a, hipStream_t st)
     return 0;
 }
 
+// k-steps of 32 the weight image of proj_patch_kernel is packed with: K rounded up, and 11 -> 12 (the kernel walks K in equal chunks)
+int proj_patch_ksteps(int K)
+{
+    const int ks = (K + 31) / 32;
+    return ks == 11 ? 12 : ks;
+}
+
 template <int KS, int NF, int HW, bool RES>
 static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 {
@@ -3435,7 +3442,7 @@ static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
 {
     if (a.B < 1 || a.CSP < 4 || a.CSP > 32 || (a.CSP & 3) || a.nparts < 1) return -11;
-    const int ks = (a.K + 31) / 32, nf = (a.N + 15) / 16;
+    const int ks = proj_patch_ksteps(a.K), nf = (a.N + 15) / 16;
 #define PP_CASE(KS_, NF_, HW_, RES_) \
     if (ks == KS_ && nf == NF_ && a.HW == HW_ && (a.res != nullptr) == RES_) return launch_proj_patch_t<KS_, NF_, HW_, RES_>(a, st);
     PP_CASE(5, 3, 784, false)    // b3: 144 -> 40 @ 28x28
@@ -3443,9 +3450,23 @@ int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
     PP_CASE(8, 5, 196, false)    // b5: 240 -> 80 @ 14x14
     PP_CASE(15, 5, 196, true)    // b6, b7: 480 -> 80
     PP_CASE(15, 7, 196, false)   // b8: 480 -> 112
-    PP_CASE(21, 7, 196, true)    // b9, b10: 672 -> 112
+    PP_CASE(21, 7, 196, true)    // b9, b10: 672 -> 112 (and B4 b11-b15)
+    PP_CASE(6, 4, 784, false)    // B4 b6: 192 -> 56 @ 28x28
+    PP_CASE(12, 4, 784, true)    // B4 b7-b9: 336 -> 56 (10.5 k-steps, padded to 12 = two chunks of 6)
+    PP_CASE(12, 7, 196, false)   // B4 b10: 336 -> 112 @ 14x14
 #undef PP_CASE
     return -5;
+}
+
+// the shapes launch_proj_patch has an instantiation for (the schedule asks before packing a layer for it)
+int proj_patch_has(int K, int N, int HW, int res)
+{
+    const int ks = proj_patch_ksteps(K), nf = (N + 15) / 16;
+    static const int T[][4] = {{5, 3, 784, 0}, {8, 3, 784, 1}, {8, 5, 196, 0}, {15, 5, 196, 1}, {15, 7, 196, 0}, {21, 7, 196, 1},
+                               {6, 4, 784, 0}, {12, 4, 784, 1}, {12, 7, 196, 0}};
+    for (auto& t : T)
+        if (t[0] == ks && t[1] == nf && t[2] == HW && t[3] == (res ? 1 : 0)) return 1;
+    return 0;
 }
 
 template <int CKS, int KSD, int CE>

@@ -525,7 +525,10 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             const int n = 16 * g + ii, k = 16 * t + 4 * qq + e;         // FC2: We[n][k] (T = g, k-group = t)
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
-            const bool pp_blk = (projse_enabled && i >= 3 && i <= 10) || (tail_enabled && i == 11);
+            // B4: squeeze-excite + project per patch wherever proj_patch_kernel has the shape (blocks 6-15) and Cs fits its 32 slots
+            const bool b4_pp = fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
+                               proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0);
+            const bool pp_blk = (projse_enabled && i >= 3 && i <= 10) || (tail_enabled && i == 11) || b4_pp;
             if ((tail_enabled && i >= 12 && i <= 15 && B.cs == 48) || pp_blk) {
                 // fp16, transposed for matrix-vector use: Wr^T [ce][csp], We^T [csp][ce] (csp = Cs padded to 4)
                 const int csp = (B.cs + 3) / 4 * 4;
@@ -575,9 +578,11 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     for (int k = 0; k < 32; ++k) wf[((k / 8) * 16 + c) * 8 + (k % 8)] = (_Float16)(float)(w[(size_t)c * 32 + k] * (1.0 / LOG2E));
                 TRY_OR_FREE(dev_upload(bb, &bb->b0_pre_w, wf));
             }
-            if (projse_enabled && i >= 3 && i <= 10) {
+            if ((projse_enabled && i >= 3 && i <= 10) ||
+                (fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
+                 proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0))) {
                 // proj_patch_kernel: fragment order as below, K and N zero-padded to whole fragments
-                const int ks32 = (B.ce + 31) / 32, nf = (B.d.cout + 15) / 16;
+                const int ks32 = proj_patch_ksteps(B.ce), nf = (B.d.cout + 15) / 16;
                 std::vector<_Float16> wf((size_t)nf * ks32 * 512, (_Float16)0.0f);
                 for (int c = 0; c < B.d.cout; ++c)
                     for (int k = 0; k < B.ce; ++k)
@@ -1010,7 +1015,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             pa.psc = (float)(1.0 / ((double)HWo * LOG2E));
             snprintf(nm, sizeof nm, "b%d.projse", i);
             char pl[48];
-            snprintf(pl, sizeof pl, "proj_patch<%d,%d,%d,%d>", (B.ce + 31) / 32, (B.d.cout + 15) / 16, HWo, B.skip ? 1 : 0);
+            snprintf(pl, sizeof pl, "proj_patch<%d,%d,%d,%d>", proj_patch_ksteps(B.ce), (B.d.cout + 15) / 16, HWo, B.skip ? 1 : 0);
             STEP(nm, pl, launch_proj_patch(pa, st));
             if (bb->keep) {
                 int r;
