@@ -166,6 +166,8 @@ int launch_stem(const uint8_t* patches, const _Float16* w, const float* bias, co
 int launch_stem_dw(const uint8_t* patches, const _Float16* w, const float* bias, const float* padval, const float* Wdw,
                    const float* bdw, _Float16* out, float* pool_part, int B, hipStream_t st);
 int launch_pw_gemm(const GemmArgs& a, hipStream_t st);
+// SE-scale + project (+ skip) for K <= 64, N <= 32 (pack_pw weights with nt = 2): one patch's pixel fragments streamed per workgroup
+int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st);
 int launch_dwconv(const DwArgs& a, hipStream_t st);
 int launch_se_gate(const float* pool_part, int nparts, int B, int C, int Cs4, const float* WrP, const float* br,
                    const float* WeP, const float* be, float* gate, hipStream_t st);

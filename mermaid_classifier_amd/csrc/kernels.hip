@@ -351,6 +351,91 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// thin_proj_kernel: SE-scale + project conv (+ skip) for layers with K <= 64 and N <= 32 on big images (B4's expand-less
+// blocks 0 and 1: 48 -> 24 and 24 -> 24 at 112x112).  pw_gemm_kernel gives such a layer one k-step of work per workgroup
+// between two barriers (0.6-1.1 TB/s measured); here a workgroup owns a run of one patch's pixel fragments, keeps the
+// 2*KSTEPS weight fragments and the patch's gate in registers, and each wave streams fragments with the next one's loads in
+// flight.  Same weight packing (pack_pw, nt = 2) and the same arithmetic order as pw_gemm_kernel<.,2,EPI_LINEAR,GATE,RES>:
+// results are bitwise identical.
+// ---------------------------------------------------------------------------------------------
+template <int KSTEPS, bool RES>
+__global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restrict__ X, int K, const _Float16* __restrict__ Wp,
+                                                        const float* __restrict__ bias, _Float16* __restrict__ Y, int N,
+                                                        const float* __restrict__ gate, int HW, int frags_per_wg,
+                                                        const _Float16* __restrict__ res)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int b = blockIdx.y;
+    const int nfrag = HW >> 4;   // HW is a multiple of 16
+    const int f0 = blockIdx.x * frags_per_wg;
+    const int f1 = f0 + frags_per_wg < nfrag ? f0 + frags_per_wg : nfrag;
+    h8 wf[KSTEPS][2];
+    f4 g0[KSTEPS], g1[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[ks][t] = *reinterpret_cast<const h8*>(Wp + ((size_t)(ks * 2 + t) * 64 + lane) * 8);
+        const int k = ks * 32 + q * 8;
+        g0[ks] = g1[ks] = (f4){0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            g0[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k);
+            g1[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k + 4);
+        }
+    }
+    const int cbase = q * 8;   // lane (m,q) owns channels 8q .. 8q+7 (4t + j) of pixel row m of the fragment
+    const f4 bv0 = *reinterpret_cast<const f4*>(bias + cbase), bv1 = *reinterpret_cast<const f4*>(bias + cbase + 4);
+    const _Float16* xb = X + (size_t)b * HW * K;
+    auto load = [&](int f, h8 (&dst)[KSTEPS], h8& r) {
+        const size_t row = (size_t)f * 16 + m;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int k = ks * 32 + q * 8;
+            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (k < K) v = *reinterpret_cast<const h8*>(xb + row * K + k);
+            dst[ks] = v;
+        }
+        if (RES) {
+            r = (h8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (cbase < N) r = *reinterpret_cast<const h8*>(res + ((size_t)b * HW + row) * N + cbase);
+        }
+    };
+    h8 xc[KSTEPS], xn[KSTEPS], rc = {0, 0, 0, 0, 0, 0, 0, 0}, rn = rc;
+    int f = f0 + wave;
+    if (f < f1) load(f, xc, rc);
+    for (; f < f1; f += 4) {
+        const bool more = f + 4 < f1;
+        if (more) load(f + 4, xn, rn);
+        f4 a0 = bv0, a1 = bv1;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            h8 v = xc[ks];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (_Float16)((float)v[j] * g0[ks][j]);
+                v[4 + j] = (_Float16)((float)v[4 + j] * g1[ks][j]);
+            }
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][0], v, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][1], v, a1, 0, 0, 0);
+        }
+        if (cbase < N) {   // N is a multiple of 8 here
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (_Float16)(a0[j] + (RES ? (float)rc[j] : 0.f));
+                o[4 + j] = (_Float16)(a1[j] + (RES ? (float)rc[4 + j] : 0.f));
+            }
+            *reinterpret_cast<h8*>(Y + ((size_t)b * HW + (size_t)f * 16 + m) * N + cbase) = o;
+        }
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) xc[ks] = xn[ks];
+            rc = rn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Depthwise KSxKS convolution, stride ST, TF-same padding, + bias (BN folded) + SiLU, fp16 out,
 // plus per-(patch, channel) partial sums of the fp32 SiLU outputs for squeeze-excite.
 // Thread = 8 channels x TW consecutive output pixels of one row; channel-group index is the fastest
@@ -3175,6 +3260,28 @@ int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
 #undef CASE_NT
 }
 
+int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
+{
+    // pack_pw layout with nt = 2, one chunk; whole 16-pixel fragments; 8-channel lanes
+    if (a.nt != 2 || a.n_chunks != 1 || a.K > 64 || (a.K & 7) || a.N > 32 || (a.N & 7) || (a.HW & 15) || !a.gate || a.epi != EPI_LINEAR ||
+        a.M != patches * a.HW)
+        return -15;
+    const int nfrag = a.HW / 16;
+    int per = 112;                          // fragments per workgroup (28 per wave)
+    if (nfrag < per) per = nfrag;
+    dim3 grid((nfrag + per - 1) / per, patches);
+    const int ks = a.Kp / 32;
+#define TP_GO(KS_, RES_) hipLaunchKernelGGL((thin_proj_kernel<KS_, RES_>), grid, dim3(256), 0, st, a.X, a.K, a.Wp, a.bias, a.Y, a.N, a.gate, a.HW, per, a.res)
+    if (ks == 1 && a.res) TP_GO(1, true);
+    else if (ks == 1) TP_GO(1, false);
+    else if (ks == 2 && a.res) TP_GO(2, true);
+    else if (ks == 2) TP_GO(2, false);
+    else return -15;
+#undef TP_GO
+    LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KS, int ST, int TW>
 static int launch_dw_t(const DwArgs& a, hipStream_t st)
 {
@@ -3351,6 +3458,8 @@ int launch_mbconv_a(const MbArgs& a, hipStream_t st)
     MB_CASE(3, 2, 2, 2, 2, 48, 14, 1)    // B4 b10
     MB_CASE(3, 1, 2, 4, 2, 96, 14, 1)    // B4 b11-b15
     MB_CASE(5, 1, 2, 5, 2, 48, 14, 1)    // B4 b17-b21
+    MB_CASE(5, 1, 2, 5, 2, 96, 14, 1)    // (MMC_B4_CC14=96)
+    MB_CASE(5, 1, 2, 4, 2, 96, 14, 1)
     MB_CASE(5, 2, 1, 5, 2, 48, 7, 1)     // B4 b22
     MB_CASE(5, 1, 1, 9, 1, 96, 7, 2)     // B4 b23-b29
     MB_CASE(3, 1, 1, 9, 1, 96, 7, 2)     // B4 b30

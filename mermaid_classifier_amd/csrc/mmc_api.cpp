@@ -184,7 +184,7 @@ static const FuseCfg B0_FUSE[16] = {
 
 // The same choices by layer geometry for the other members of the family (B4): the tile and chunk B0 uses at that
 // resolution / stride / kernel size, with CC a divisor of the expanded width.
-static FuseCfg generic_fuse_cfg(int H, int k, int s, int ce)
+static FuseCfg generic_fuse_cfg(int H, int k, int s, int ce, int cc5)
 {
     FuseCfg fc{0, 0, 0, 0, 1, 0};
     if (H == 112 && s == 2) fc = {8, 8, 48, 2, 1, 0};
@@ -192,7 +192,7 @@ static FuseCfg generic_fuse_cfg(int H, int k, int s, int ce)
     else if (H == 56 && s == 2) fc = {4, 14, 48, 2, 1, 0};
     else if (H == 28 && s == 1) fc = {14, 14, 48, 2, 1, 0};
     else if (H == 28 && s == 2) fc = {2, 14, 48, 2, 1, 0};
-    else if (H == 14 && s == 1) fc = {14, 14, k == 3 ? 96 : 48, 2, 1, 0};
+    else if (H == 14 && s == 1) fc = {14, 14, k == 3 ? 96 : cc5, 2, 1, 0};
     else if (H == 14 && s == 2) fc = {7, 7, 48, 1, 1, 0};
     else if (H == 7 && s == 1) fc = {7, 7, 96, 1, 2, 0};
     if (fc.CC && ce % fc.CC) fc.TH = 0;
@@ -249,6 +249,7 @@ struct mmc_backbone {
     bool mb1 = false;                // block 1 on mb1_kernel (window-in-registers depthwise) instead of mbconv_a PRE
     bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
     int mid14_last = 8;              // ... for blocks 6..mid14_last
+    bool thin_proj = true;           // B4 blocks 0/1: thin_proj_kernel instead of pw_gemm for the tiny-K project convs (MMC_THIN_PROJ=0)
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
     bool tail_full = false;
@@ -433,6 +434,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
     const bool fuse_generic = !is_b0 && !(fuse_env && fuse_env[0] == '0');   // B4: fused expand+depthwise where an instantiation fits
+    const int b4_cc14 = [] { const char* e = getenv("MMC_B4_CC14"); return e && atoi(e) == 48 ? 48 : 96; }();   // 5x5 layers at 14x14: 96 measured +1.3 %
+    { const char* e = getenv("MMC_THIN_PROJ"); bb->thin_proj = !(e && e[0] == '0'); }
     bb->fuse_stem = fuse_enabled;
     const char* pp_env = getenv("MMC_PROJSE");
     const bool projse_enabled = fuse_enabled && !(pp_env && pp_env[0] == '0');
@@ -626,7 +629,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         B.iters = passes >= 8 ? 4 : 1;
         B.parts = (passes + B.iters - 1) / B.iters;
         if (B.has_expand && ((fuse_enabled && i < 16) || fuse_generic)) {
-            FuseCfg fc = is_b0 ? B0_FUSE[i] : generic_fuse_cfg(H, B.d.k, B.d.s, B.ce);
+            FuseCfg fc = is_b0 ? B0_FUSE[i] : generic_fuse_cfg(H, B.d.k, B.d.s, B.ce, b4_cc14);
             if (const char* ov = getenv("MMC_FUSE_CFG")) {   // "i:TH,TWo,CC;..." experiment override
                 char key[16];
                 snprintf(key, sizeof key, "%d:", i);
@@ -1042,6 +1045,15 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
         if (i == 0 && bb->fuse_b0b1 && stem_fused) continue;   // block 0's project runs inside block 1's kernel
         snprintf(nm, sizeof nm, "b%d.project", i);
+        if (bb->thin_proj && bb->arch != MMC_ARCH_B0 && B.project.nt == 2 && B.project.n_chunks == 1 && B.project.K <= 64 && B.project.N <= 32 &&
+            (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136) {
+            // tiny-K, tiny-N project on a big image (B4 blocks 0, 1): stream one patch's fragments per workgroup
+            GemmArgs a{};
+            a.X = ws.dwbuf; a.M = n * HWo; a.K = B.project.K; a.Wp = B.project.w; a.Kp = B.project.Kp; a.bias = B.project.b; a.Y = y;
+            a.N = B.project.N; a.nt = B.project.nt; a.n_chunks = B.project.n_chunks; a.epi = EPI_LINEAR; a.gate = ws.gate; a.HW = HWo;
+            a.res = B.skip ? x : nullptr;
+            STEP(nm, "thin_proj", launch_thin_proj(a, n, st));
+        } else
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
         snprintf(nm, sizeof nm, "b%d.out", i);
         if (bb->keep) { int r = save_act(bb, nm, y, (size_t)n * HWo * B.d.cout, true, st); if (r) return r; }

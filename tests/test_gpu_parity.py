@@ -301,6 +301,34 @@ def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_bac
         assert np.array_equal(got, base)          # lanes only split the batch: bitwise identical
 
 
+@pytest.mark.parametrize("knob", ["MMC_THIN_PROJ", "MMC_PROJSE", "MMC_FUSE", "MMC_B4_CC14=48", "MMC_LANES"])
+def test_b4_schedule_variants(synth_sd_b4, knob, monkeypatch):
+    """B4's schedule switches: thin_proj reproduces pw_gemm bit for bit (same packing, same arithmetic order), lanes only
+    split the batch; proj_patch / the fused expand+depthwise / the chunk width change rounding points only."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    sd = {k: v.numpy() for k, v in synth_sd_b4.items()}
+    p = ref.natural_patches(4, seed=7)[[0, 1, 3]]          # the well-conditioned inputs (see test_b4_backbone_matches_oracle)
+    bb = Backbone(sd, device=0, max_batch=4)
+    base = bb.extract(p)
+    bb.close()
+    if "=" in knob:
+        monkeypatch.setenv(*knob.split("="))
+    else:
+        monkeypatch.setenv(knob, "1" if knob == "MMC_LANES" else "0")
+    bb = Backbone(sd, device=0, max_batch=4)
+    try:
+        got = bb.extract(p)
+    finally:
+        bb.close()
+    if knob in ("MMC_THIN_PROJ", "MMC_LANES"):
+        assert np.array_equal(got, base)
+    else:
+        assert rel_l2(got, base).max() < TOL_NATURAL
+    want = np.load(GOLDEN / "backbone_b4_features.npz")["natural4"][[0, 1, 3]]
+    assert rel_l2(got, want).max() < TOL_NATURAL and cosine(got, want).min() >= COS_GATE
+
+
 def test_graph_replay_is_bitwise_identical_to_plain_launches(checkpoint_path, monkeypatch):
     """A pass over buffers that repeat is captured into a HIP graph on the third call and replayed afterwards
     (mmc_api.cpp run_pass); replay, plain launches (MMC_GRAPH=0) and a call with fresh buffers must agree bitwise."""

@@ -33,7 +33,10 @@ def main():
     print(f"B4 batch {a.batch}: {dt*1e3:.2f} ms/pass -> {a.batch/dt:.0f} patches/s ({a.batch/dt*3.0e9/1e12:.1f} TFLOP/s at 3.00 GFLOP/patch); "
           f"workspace {bb.workspace_bytes/2**30:.2f} GiB, lanes {bb.lanes}")
     per = defaultdict(float)
-    for name, ms in bb.profile(p, f):
+    prof = bb.profile(p, f)
+    top = sorted(prof, key=lambda kv: -kv[1])[:14]
+    print("  slowest launches (one lane of", a.batch // bb.lanes, "patches):", ", ".join(f"{n.split('|')[0]}={ms*1e3:.0f}us" for n, ms in top))
+    for name, ms in prof:
         kern = name.split("|")[1]
         kind = name.split("|")[0].split(".")[-1]
         per[f"{kind}:{kern.split('<')[0]}"] += ms
