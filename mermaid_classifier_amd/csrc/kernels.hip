@@ -3263,11 +3263,13 @@ int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
 int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
 {
     // pack_pw layout with nt = 2, one chunk; whole 16-pixel fragments; 8-channel lanes
-    if (a.nt != 2 || a.n_chunks != 1 || a.K > 64 || (a.K & 7) || a.N > 32 || (a.N & 7) || (a.HW & 15) || !a.gate || a.epi != EPI_LINEAR ||
+    if (a.nt != 2 || a.n_chunks != 1 || a.K > 192 || (a.K & 7) || a.N > 32 || (a.N & 7) || (a.HW & 15) || !a.gate || a.epi != EPI_LINEAR ||
         a.M != patches * a.HW)
         return -15;
     const int nfrag = a.HW / 16;
-    int per = 112;                          // fragments per workgroup (28 per wave)
+    int per = (int)(((long)nfrag * patches / 2048 + 3) / 4 * 4);   // fragments per workgroup: ~2048 workgroups, whole rounds of 4 waves
+    if (per < 8) per = 8;
+    if (per > 112) per = 112;
     if (nfrag < per) per = nfrag;
     dim3 grid((nfrag + per - 1) / per, patches);
     const int ks = a.Kp / 32;
@@ -3276,6 +3278,12 @@ int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
     else if (ks == 1) TP_GO(1, false);
     else if (ks == 2 && a.res) TP_GO(2, true);
     else if (ks == 2) TP_GO(2, false);
+    else if (ks == 3 && a.res) TP_GO(3, true);
+    else if (ks == 3) TP_GO(3, false);
+    else if (ks == 5 && a.res) TP_GO(5, true);
+    else if (ks == 5) TP_GO(5, false);
+    else if (ks == 6 && a.res) TP_GO(6, true);
+    else if (ks == 6) TP_GO(6, false);
     else return -15;
 #undef TP_GO
     LAUNCH_CHECK();
