@@ -178,7 +178,7 @@ struct BlockW {
 struct FuseCfg { int TH, TWo, CC, TW, PB, WLDS; };
 static const FuseCfg B0_FUSE[16] = {
     {0, 0, 0, 0, 1, 0},     {8, 8, 48, 2, 1, 0},    {14, 14, 48, 2, 1, 0},  {4, 14, 48, 2, 1, 0},   {14, 14, 48, 2, 1, 0},
-    {2, 14, 80, 2, 1, 0},   {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 48, 2, 1, 0},  {14, 14, 48, 2, 1, 0},
+    {7, 14, 80, 2, 1, 0},   {14, 14, 96, 2, 1, 0},  {14, 14, 96, 2, 1, 0},  {14, 14, 48, 2, 1, 0},  {14, 14, 48, 2, 1, 0},
     {14, 14, 48, 2, 1, 0},  {7, 7, 48, 1, 1, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},    {7, 7, 96, 1, 2, 0},
     {7, 7, 96, 1, 2, 0}};
 
