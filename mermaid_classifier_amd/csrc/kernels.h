@@ -133,6 +133,7 @@ struct Mid14Args {
     float* pool;              // [B][Ce] pool sums
     int B, Cin, Ce, ks;
     int nsplit;               // workgroups per patch (each takes every nsplit-th chunk of 96 channels)
+    int stride;               // 1, or 2 (block 11: D is [B][49][Ce])
 };
 int launch_mid14(const Mid14Args& a, hipStream_t st);
 

@@ -2265,10 +2265,15 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 //            channels: 128-byte segments); pool sums per band -> LDS -> one value per channel.
 // Output: D[B][196][CE] and pool[B][CE] -- what proj_patch_kernel consumes.
 // ---------------------------------------------------------------------------------------------
-template <int CKS, int KSD, int CE>
+// ST = 2 (block 11: 5x5 stride 2, 14x14 -> 7x7, TF-same pad 1): the same expand; a depthwise thread = (channel, band of 2
+// output rows) with the same 7x7 pixel-pair window (input rows 4*band-1 .. 4*band+5); output x reads pairs x-1, x, x+1 with the
+// tap pairs (0,k0), (k1,k2), (k3,k4) -- the odd-x variant of the stride-1 taps; four bands, output D[B][49][CE].
+template <int CKS, int KSD, int CE, int ST = 1>
 __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 {
+    static_assert(ST == 1 || (ST == 2 && KSD == 5), "stride 2 is the 5x5 block 11");
     constexpr int HW = 196, CH = 96, NCHK = CE / CH, NPF = 13, NTILE = 6 * NPF;
+    constexpr int HWO = ST == 1 ? 196 : 49, NBAND = ST == 1 ? 5 : 4;
     constexpr int ES = CH * 2 + 16;         // bytes per E row
     constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2;
     static_assert(CE % CH == 0, "chunking");
@@ -2290,7 +2295,7 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     const GLOBAL_AS _Float16* xgp = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * Cin;
     // depthwise role of this thread: channel cd of the chunk, output rows rb .. rb+2 (band 4: rows 12, 13)
     const int band = tid / CH, cd = tid - band * CH;
-    const bool dw_thr = tid < 5 * CH;
+    const bool dw_thr = tid < NBAND * CH;
     const int rb = 3 * band;
 #pragma unroll 1
     for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
@@ -2355,12 +2360,12 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         // ---------------- depthwise ----------------
         float psum = 0.f;
         {
-            constexpr int NR = 3 + 2 * R;   // input rows of a 3-row band
+            constexpr int NR = ST == 1 ? 3 + 2 * R : 7;   // input rows of a band (3 output rows; stride 2: 2 output rows)
             const unsigned char* col = E + 2 * cd;
             uint32_t P[NR][7];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const int iy = rb - R + r;
+                const int iy = (ST == 1 ? rb - R : 4 * band - 1) + r;
                 const bool rok = iy >= 0 && iy < 14;
                 const unsigned char* rowp = col + (rok ? iy : 0) * (14 * ES);
 #pragma unroll
@@ -2370,7 +2375,38 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                     P[r][pp] = rok ? (lo | (hi << 16)) : 0u;
                 }
             }
-            _Float16* dg = a.D + (size_t)b * HW * CE + chunk * CH + cd;
+            _Float16* dg = a.D + (size_t)b * HWO * CE + chunk * CH + cd;
+            if (ST == 2) {
+#pragma unroll
+                for (int ro = 0; ro < 2; ++ro) {
+                    const int oy = 2 * band + ro;
+                    if (oy < 7) {
+                        float acc[7];
+#pragma unroll
+                        for (int ox = 0; ox < 7; ++ox) acc[ox] = dbias;
+#pragma unroll
+                        for (int ky = 0; ky < 5; ++ky) {
+                            const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                            const uint32_t wq[3] = {r0 << 16, __builtin_amdgcn_alignbit(r1, r0, 16), __builtin_amdgcn_alignbit(r2, r1, 16)};
+#pragma unroll
+                            for (int ip = 0; ip < 3; ++ip)
+#pragma unroll
+                                for (int ox = 0; ox < 7; ++ox) {
+                                    const int xpc = ox - 1 + ip;
+                                    if (xpc < 0 || xpc > 6) continue;
+                                    acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
+                                                                     *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
+                                }
+                        }
+#pragma unroll
+                        for (int ox = 0; ox < 7; ++ox) {
+                            const float y = silu_scaled(acc[ox]);
+                            psum += y;
+                            if (dw_thr) dg[(size_t)(oy * 7 + ox) * CE] = (_Float16)y;
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int ro = 0; ro < 3; ++ro) {
                 const int oy = rb + ro;
@@ -2415,9 +2451,7 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         T7_BAR();
         if (tid < CH)
             a.pool[(size_t)b * CE + chunk * CH + tid] =
-                (((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid]) + pband[4 * CH + tid];
-        // (the next chunk's expand writes E only after every wave passed the barrier above; pband is rewritten only
-        // after the next chunk's first barrier)
+                ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid] + (NBAND == 5 ? pband[4 * CH + tid] : 0.f);
         // (the next chunk's expand writes E only after every wave passed the barrier above; pband is rewritten only
         // after the next chunk's first barrier)
     }
@@ -3587,18 +3621,18 @@ int proj_patch_has(int K, int N, int HW, int res)
     return 0;
 }
 
-template <int CKS, int KSD, int CE>
+template <int CKS, int KSD, int CE, int ST = 1>
 static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
 {
     const int lds = 196 * (96 * 2 + 16) + 5 * 96 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE, ST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mid14_kernel<CKS, KSD, CE>), dim3(a.B, a.nsplit < 1 ? 1 : a.nsplit), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((mid14_kernel<CKS, KSD, CE, ST>), dim3(a.B, a.nsplit < 1 ? 1 : a.nsplit), dim3(512), lds, st, a);
     LAUNCH_CHECK();
     return 0;
 }
@@ -3607,6 +3641,10 @@ int launch_mid14(const Mid14Args& a, hipStream_t st)
 {
     if (a.B < 1) return -14;
     const int cks = (a.Cin + 31) / 32;
+    if (a.stride == 2) {
+        if (cks == 4 && a.ks == 5 && a.Ce == 672) return launch_mid14_t<4, 5, 672, 2>(a, st);   // b11
+        return -5;
+    }
     if (cks == 4 && a.ks == 5 && a.Ce == 672) return launch_mid14_t<4, 5, 672>(a, st);   // b9, b10
     if (cks == 3 && a.ks == 5 && a.Ce == 480) return launch_mid14_t<3, 5, 480>(a, st);   // b8
     if (cks == 3 && a.ks == 3 && a.Ce == 480) return launch_mid14_t<3, 3, 480>(a, st);   // b6, b7

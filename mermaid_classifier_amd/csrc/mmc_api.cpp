@@ -249,6 +249,7 @@ struct mmc_backbone {
     bool mb1 = false;                // block 1 on mb1_kernel (window-in-registers depthwise) instead of mbconv_a PRE
     bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
     int mid14_last = 8;              // ... for blocks 6..mid14_last
+    bool mid14_b11 = false;          // ... and block 11 (5x5 stride 2) on mid14_kernel<4,5,672,2>
     bool thin_proj = true;           // B4 blocks 0/1: thin_proj_kernel instead of pw_gemm for the tiny-K project convs (MMC_THIN_PROJ=0)
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
@@ -445,6 +446,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const bool mid14_enabled = mid14_mode != 0;
     bb->mid14 = mid14_enabled;
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
+    { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
     const char* mbt_env = getenv("MMC_MBT");
     const bool mbt_enabled = fuse_enabled && (mbt_env && mbt_env[0] == '1');
     bb->mbt = mbt_enabled;
@@ -486,7 +488,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if ((tail_enabled && i >= 12 && i <= 15) || (mid14_enabled && i >= 6 && i <= 10) || (mbt_enabled && (i == 2 || i == 4))) {
+            if ((tail_enabled && i >= 12 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && (i == 2 || i == 4))) {
                 // taps of tail7_kernel / mid14_kernel / mbt_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
@@ -922,11 +924,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             nparts = (B.H / 14) * (B.H / 28);
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             STEP(nm, "mbt", launch_mbt(ta, st));
-        } else if (B.fused && bb->mid14 && i >= 6 && i <= bb->mid14_last && B.t_dwp && B.exp_frag) {
+        } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
             Mid14Args ma{};
             ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
             ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
-            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : 4; }
+            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (B.d.s == 2 ? 7 : 4); }
+            ma.stride = B.d.s;
             nparts = 1;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             STEP(nm, "mid14", launch_mid14(ma, st));
