@@ -82,6 +82,12 @@ struct TailArgs {
     const float* pre_br;        // [28+]
     const _Float16* pre_we_t;   // [28][672]
     const float* pre_be;        // [672]
+    // ... or the whole of block 11 from its INPUT (pre_X instead of pre_D / pre_pool): expand 112 -> 672 + depthwise 5x5 stride 2 in LDS
+    const _Float16* pre_X;      // [B][196][112] block 11's input, or null
+    const _Float16* pre_wexp;   // [42][4][64][8] expand weights, MFMA fragment order
+    const float* pre_bexp;      // [672]
+    const uint32_t* pre_dwp;    // [15][672] depthwise taps as fp16 pairs (layout of TailBlock::dwp)
+    const float* pre_bdw;       // [672]
     const _Float16* pre_wproj;  // [12][24][64][8] (k-steps 21..23 zero)
     const float* pre_bproj;     // [192]
     // optional head: conv 320 -> 1280 + swish + average pool -> feat

@@ -1603,6 +1603,7 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 #define T7_XS 400                                    // X row stride, bytes
 #define T7_ES 2320                                   // ED row stride, bytes (580 dwords = 4 mod 64 banks)
 #define T7_YS 656                                    // row stride of b15's 320-channel output (parked in ED)
+#define T7_DS11 1552                                 // row stride of block 11's depthwise output when it is produced in LDS (24 k-steps + 16)
 #define T7_OFF_X (T7_PIX * T7_ES)
 #define T7_OFF_POOL (T7_OFF_X + T7_PIX * T7_XS)
 #define T7_OFF_GATE (T7_OFF_POOL + T7_CE * 4)
@@ -1661,7 +1662,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
     // KS (k-steps, a multiple of 4) pixel fragments come from ED one k-step ahead of their MFMAs, weight fragments four
     // k-steps ahead.  The K order is part of the result: same for every workgroup.
     auto proj_run = [&](const GLOBAL_AS _Float16* wproj, int KS, int mode, int nf0, int nfn, int lane, int m, int q,
-                        const int (&pixc)[4], f4 (&pbias)[3], unsigned (&wo)[3], h8 (&wa)[3][4]) {
+                        const int (&pixc)[4], f4 (&pbias)[3], unsigned (&wo)[3], h8 (&wa)[3][4], int es = T7_ES) {
         f4 acc[3][4];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -1669,7 +1670,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int pf = 0; pf < 4; ++pf) acc[i][pf] = pbias[i];
         const unsigned char* bxp[4];
 #pragma unroll
-        for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * T7_ES + 16 * q;
+        for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * es + 16 * q;
         // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside one
         auto k_loop = [&](auto nf_tag) {
             constexpr int NF = decltype(nf_tag)::value;
@@ -1735,9 +1736,11 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
         }
     };
-    if (a.pre_D) {
-        // ---- block 11, second half (its depthwise output D11[49][672] and pool sums come from mbconv_a_kernel):
-        //      squeeze-excite, gate, project 672 -> 192 (no skip) -> X.  Same recipes as in the block loop below. ----
+    if (a.pre_D || a.pre_X) {
+        // ---- block 11, second half (its depthwise output D11[49][672] and pool sums come from mbconv_a_kernel, or are
+        //      produced right here from the block's input when pre_X is given): squeeze-excite, gate, project
+        //      672 -> 192 (no skip) -> X.  Same recipes as in the block loop below. ----
+        const int DS = a.pre_X ? T7_DS11 : T7_ES;   // row stride of D11 in LDS
         const int tid = tid0, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int m = lane & 15, q = lane >> 4;
         const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.pre_wr_t);
@@ -1755,7 +1758,142 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)((j * 672 + (fc_thr ? 2 * tid : 0)) * 2));
         const float be0 = fc_thr ? a.pre_be[2 * tid] : 0.f, be1 = fc_thr ? a.pre_be[2 * tid + 1] : 0.f;
         const float brv = tid < 28 ? a.pre_br[tid] : 0.f;
-        {
+        if (a.pre_X) {
+            // ---- block 11, FIRST half, inside the workgroup (the recipe of mid14_kernel<4,5,672,2>): the block input
+            //      X11[196][112] goes to registers as pixel fragments once; per chunk of 96 expanded channels: expand (MFMA,
+            //      weight fragments from L2 one ahead) -> silu -> E[196][96] in LDS -> depthwise 5x5 stride 2 (thread =
+            //      channel x 2 output rows, 7x7 pixel-pair window in registers, v_dot2c) -> silu -> D11[49][672] compact in
+            //      LDS + pool sums.  No launch, no D11 / pool tensor in HBM, no second read of them. ----
+            constexpr int CH = 96, ES11 = CH * 2 + 16;
+            unsigned char* EB = ED + T7_PIX * T7_DS11;         // [196][96] expanded chunk, behind the compact D11
+            float* pband = part;                               // [4][96] pool partials of the row bands
+            const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.pre_wexp);
+            const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.pre_bexp);
+            const GLOBAL_AS uint32_t* dwp = sgpr_ptr<uint32_t>(a.pre_dwp);
+            const GLOBAL_AS float* bdw = sgpr_ptr<float>(a.pre_bdw);
+            const GLOBAL_AS _Float16* xgp = sgpr_ptr<_Float16>(a.pre_X) + (size_t)b * 196 * 112;
+            const int npf = wave < 5 ? 2 : 1;
+            const int pf0 = wave < 5 ? 2 * wave : wave + 5;
+            h8 xb[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pix = 16 * (pf0 + (i < npf ? i : 0)) + m;
+                const int pixc = pix < 196 ? pix : 195;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = 32 * ks + 8 * q;
+                    const u4v rawx = gload<u4v>(xgp, (unsigned)((pixc * 112 + (kk < 112 ? kk : 104)) * 2));
+                    const uint32_t keep = kk < 112 ? 0xffffffffu : 0u;
+                    const u4v mk = {rawx.x & keep, rawx.y & keep, rawx.z & keep, rawx.w & keep};
+                    xb[i][ks] = *reinterpret_cast<const h8*>(&mk);
+                }
+            }
+            for (int e = tid; e < T7_PIX * 12; e += 512) {   // k-steps 21..23 of D11 are zeros
+                const int pix = e / 12, oc = e - pix * 12;
+                *reinterpret_cast<uint4*>(ED + pix * T7_DS11 + 1344 + oc * 16) = uint4{0u, 0u, 0u, 0u};
+            }
+            const int band = tid / CH, cd = tid - band * CH;
+            const bool dw_thr = tid < 4 * CH;
+            h8 wn[4];   // weight fragments one ahead -- across the chunk boundary too (fragment 42 = fragment 41 re-read, unused)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((ks * 64 + lane) * 16));
+#pragma unroll 1
+            for (int chunk = 0; chunk < 7; ++chunk) {
+                uint32_t raw[15];
+                const int cg = chunk * CH + (dw_thr ? cd : 0);
+#pragma unroll
+                for (int i = 0; i < 15; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * 672 + cg) * 4u);
+                const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
+                {
+#pragma unroll
+                    for (int nf = 0; nf < 6; ++nf) {
+                        const int nfg = 6 * chunk + nf;
+                        h8 wc[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
+                        {
+                            const int nxt = nfg + 1 < 42 ? nfg + 1 : 41;
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)(((nxt * 4 + ks) * 64 + lane) * 16));
+                        }
+                        const f4 bv = gload<f4>(bexp, (unsigned)(16 * nfg + 4 * q) * 4u);
+                        f4 acc[2] = {bv, bv};
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[0][ks], acc[0], 0, 0, 0);
+                            if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[1][ks], acc[1], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int pix = 16 * (pf0 + i) + m;
+                            if (i < npf && pix < 196) {
+                                h4 o;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[i][j]);
+                                *reinterpret_cast<h4*>(EB + pix * ES11 + (16 * nf + 4 * q) * 2) = o;
+                            }
+                        }
+                    }
+                }
+                T7_BAR();
+                float psum = 0.f;
+                {
+                    const unsigned char* col = EB + 2 * cd;
+                    uint32_t P[7][7];
+#pragma unroll
+                    for (int r = 0; r < 7; ++r) {
+                        const int iy = 4 * band - 1 + r;
+                        const bool rok = iy >= 0 && iy < 14;
+                        const unsigned char* rowp = col + (rok ? iy : 0) * (14 * ES11);
+#pragma unroll
+                        for (int pp = 0; pp < 7; ++pp) {
+                            const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES11);
+                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES11);
+                            P[r][pp] = rok ? (lo | (hi << 16)) : 0u;
+                        }
+                    }
+#pragma unroll
+                    for (int ro = 0; ro < 2; ++ro) {
+                        const int oy = 2 * band + ro;
+                        if (oy < 7) {
+                            float acc[7];
+#pragma unroll
+                            for (int ox = 0; ox < 7; ++ox) acc[ox] = dbias;
+#pragma unroll
+                            for (int ky = 0; ky < 5; ++ky) {
+                                const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                                const uint32_t wq[3] = {r0 << 16, __builtin_amdgcn_alignbit(r1, r0, 16), __builtin_amdgcn_alignbit(r2, r1, 16)};
+#pragma unroll
+                                for (int ip = 0; ip < 3; ++ip)
+#pragma unroll
+                                    for (int ox = 0; ox < 7; ++ox) {
+                                        const int xpc = ox - 1 + ip;
+                                        if (xpc < 0 || xpc > 6) continue;
+                                        acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
+                                                                         *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
+                                    }
+                            }
+#pragma unroll
+                            for (int ox = 0; ox < 7; ++ox) {
+                                const float y = silu_scaled(acc[ox]);
+                                psum += y;
+                                if (dw_thr) *reinterpret_cast<_Float16*>(ED + (oy * 7 + ox) * T7_DS11 + (chunk * CH + cd) * 2) = (_Float16)y;
+                            }
+                        }
+                    }
+                    if (dw_thr) pband[band * CH + cd] = psum;
+                }
+                T7_BAR();
+                if (tid < CH) pooled[chunk * CH + tid] = ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid];
+            }
+            if (a.dbg_dw) {   // per-tensor mode: block 11's depthwise output as the separate kernels would have stored it
+                T7_BAR();
+                for (int e = tid; e < T7_PIX * 84; e += 512) {
+                    const int pix = e / 84, oc = e - pix * 84;
+                    *reinterpret_cast<uint4*>(a.dbg_dw + ((size_t)b * T7_PIX + pix) * 672 + oc * 8) = *reinterpret_cast<const uint4*>(ED + pix * T7_DS11 + oc * 16);
+                }
+            }
+        } else {
             const _Float16* dg = a.pre_D + (size_t)b * T7_PIX * 672;
             for (int e = tid; e < T7_PIX * 96; e += 512) {   // 84 real 16-byte columns + 12 of zeros (k-steps 21..23)
                 const int pix = e / 96, oc = e - pix * 96;
@@ -1816,13 +1954,13 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         T7_BAR();
         for (int e = tid; e < T7_PIX * 84; e += 512) {
             const int pix = e / 84, oc = e - pix * 84;
-            uint4* pv = reinterpret_cast<uint4*>(ED + pix * T7_ES + oc * 16);
+            uint4* pv = reinterpret_cast<uint4*>(ED + pix * DS + oc * 16);
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
             const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
             *pv = gate_h8(*pv, g0, g1);
         }
         T7_BAR();
-        proj_run(wproj, 24, 2, nf0, nfn, lane, m, q, pixc, pbias, wo, wa);
+        proj_run(wproj, 24, 2, nf0, nfn, lane, m, q, pixc, pbias, wo, wa, DS);
         T7_BAR();
     } else if (a.in_wide) {
         // head-only use (per-tensor tests): the input is block 15's output [49][320]
@@ -3554,7 +3692,8 @@ int launch_mbconv_d(const MbArgs& a, hipStream_t st)
 int launch_tail7(const TailArgs& a, hipStream_t st)
 {
     if (a.nblk < 0 || a.nblk > 4 || a.B < 1) return -9;
-    if (a.nblk == 0 && !a.pre_D && !a.head_w) return -9;
+    if (a.nblk == 0 && !a.pre_D && !a.pre_X && !a.head_w) return -9;
+    if (a.pre_X && (!a.pre_wexp || !a.pre_bexp || !a.pre_dwp || !a.pre_bdw)) return -9;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel),

@@ -254,6 +254,7 @@ struct mmc_backbone {
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
     bool tail_full = false;
+    bool tail_b11 = false;           // block 11's front half (expand + depthwise stride 2) inside tail7_kernel too: no b11 launch at all
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     std::map<std::string, Saved> saved;
@@ -488,7 +489,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if ((tail_enabled && i >= 12 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && (i == 2 || i == 4))) {
+            if ((tail_enabled && i >= 11 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && (i == 2 || i == 4))) {
                 // taps of tail7_kernel / mid14_kernel / mbt_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
@@ -747,6 +748,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             const BlockW& B11 = bb->blk[11];
             bb->tail_full = !(tf && tf[0] == '0') && bb->pre_wproj && bb->head_wfrag && B11.t_wr && B11.pp_csp == 28 && B11.fused &&
                             B11.f_tiles_x * B11.f_tiles_y == 1;
+            const char* tb = getenv("MMC_TAIL_B11");
+            bb->tail_b11 = bb->tail_full && !(tb && tb[0] == '0') && B11.exp_frag && B11.t_dwp && B11.f_ksteps == 4 && B11.ce == 672 &&
+                           B11.d.k == 5 && B11.d.s == 2 && B11.H == 14;
         }
     }
     {
@@ -911,6 +915,18 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
+        if (i == 11 && bb->tail_full && bb->tail_b11 && !bb->keep) {
+            // the whole of block 11, blocks 12..15 and the head conv in ONE launch: from block 10's output to the feature vector
+            TailArgs ta{};
+            ta.B = n; ta.blk = bb->tail_tab; ta.nblk = 4;
+            ta.pre_X = x; ta.pre_wexp = B.exp_frag; ta.pre_bexp = B.expand.b; ta.pre_dwp = B.t_dwp; ta.pre_bdw = B.dw_b;
+            ta.pre_wr_t = B.t_wr; ta.pre_br = B.pp_br; ta.pre_we_t = B.t_we; ta.pre_be = B.se_be; ta.pre_wproj = bb->pre_wproj;
+            ta.pre_bproj = B.project.b; ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
+            ta.head_w = bb->head_wfrag; ta.head_b = bb->head.b; ta.feat = out_dev;
+            STEP("b11all-head.tail", "tail7", launch_tail7(ta, st));
+            tail_done = true;
+            break;
+        }
         if (i == 0 && stem_fused) {
             // with block 0's project folded into block 1's kernel the depthwise output goes to the spare activation
             // buffer (block 1 reads it while writing its own depthwise output to dwbuf)

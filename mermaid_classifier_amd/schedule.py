@@ -61,6 +61,11 @@ def b0_launches(batch: int) -> List[Launch]:
     out.append(Launch("b11-head.tail", "tail", batch * (49 * 672 * 2 + 672 * 4 + FEATURE_DIM * 4) + w_bytes
                       + 192 * 672 * 2 + 2 * 28 * 672 * 2 + FEATURE_DIM * 320 * 2,
                       sum(l.flops for l in tail) + sum(l.flops for l in b11) + head_flops))
+    # ... and with block 11's front half (expand + depthwise stride 2) inside as well: from block 10's output to the features
+    b11f = [l for l in out if l.name == "b11.mbconv"]
+    out.append(Launch("b11all-head.tail", "tail", batch * (196 * 112 * 2 + FEATURE_DIM * 4) + w_bytes
+                      + 672 * 112 * 2 + 15 * 672 * 4 + 192 * 672 * 2 + 2 * 28 * 672 * 2 + FEATURE_DIM * 320 * 2,
+                      sum(l.flops for l in tail) + sum(l.flops for l in b11) + sum(l.flops for l in b11f) + head_flops))
     out.append(Launch("head", "head", batch * h * h * 320 * 2 + batch * FEATURE_DIM * 4 + FEATURE_DIM * 320 * 2,
                       2 * batch * h * h * 320 * FEATURE_DIM))
     return out
