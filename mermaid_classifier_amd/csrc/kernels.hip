@@ -1764,8 +1764,8 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             //      weight fragments from L2 one ahead) -> silu -> E[196][96] in LDS -> depthwise 5x5 stride 2 (thread =
             //      channel x 2 output rows, 7x7 pixel-pair window in registers, v_dot2c) -> silu -> D11[49][672] compact in
             //      LDS + pool sums.  No launch, no D11 / pool tensor in HBM, no second read of them. ----
-            constexpr int CH = 96, ES11 = CH * 2 + 16;
-            unsigned char* EB = ED + T7_PIX * T7_DS11;         // [196][96] expanded chunk, behind the compact D11
+            constexpr int CH = 96, ES2 = 416;                  // E2[98 pixel pairs][96 channels], one dword per pair (as in mid14_kernel)
+            unsigned char* EB = ED + T7_PIX * T7_DS11;         // expanded chunk, behind the compact D11
             float* pband = part;                               // [4][96] pool partials of the row bands
             const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.pre_wexp);
             const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.pre_bexp);
@@ -1816,21 +1816,23 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll
                             for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)(((nxt * 4 + ks) * 64 + lane) * 16));
                         }
-                        const f4 bv = gload<f4>(bexp, (unsigned)(16 * nfg + 4 * q) * 4u);
+                        const float bs = gload<float>(bexp, (unsigned)(16 * nfg + m) * 4u);
+                        const f4 bv = {bs, bs, bs, bs};
                         f4 acc[2] = {bv, bv};
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[0][ks], acc[0], 0, 0, 0);
-                            if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[1][ks], acc[1], 0, 0, 0);
+                        for (int ks = 0; ks < 4; ++ks) {   // un-swapped: lane (m, q) = channel 16 nf + m of pixels 16 pf + 4q .. +3
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0][ks], wc[ks], acc[0], 0, 0, 0);
+                            if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[1][ks], wc[ks], acc[1], 0, 0, 0);
                         }
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            const int pix = 16 * (pf0 + i) + m;
-                            if (i < npf && pix < 196) {
-                                h4 o;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[i][j]);
-                                *reinterpret_cast<h4*>(EB + pix * ES11 + (16 * nf + 4 * q) * 2) = o;
+                            const int pix0 = 16 * (pf0 + i) + 4 * q;
+                            if (i < npf && pix0 < 196) {
+                                h2 p0 = {(_Float16)silu_scaled(acc[i][0]), (_Float16)silu_scaled(acc[i][1])};
+                                h2 p1 = {(_Float16)silu_scaled(acc[i][2]), (_Float16)silu_scaled(acc[i][3])};
+                                unsigned char* dst = EB + (pix0 >> 1) * ES2 + (16 * nf + m) * 4;
+                                *reinterpret_cast<h2*>(dst) = p0;
+                                *reinterpret_cast<h2*>(dst + ES2) = p1;
                             }
                         }
                     }
@@ -1838,18 +1840,17 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 T7_BAR();
                 float psum = 0.f;
                 {
-                    const unsigned char* col = EB + 2 * cd;
+                    const unsigned char* col = EB + 4 * cd;
                     uint32_t P[7][7];
 #pragma unroll
                     for (int r = 0; r < 7; ++r) {
                         const int iy = 4 * band - 1 + r;
                         const bool rok = iy >= 0 && iy < 14;
-                        const unsigned char* rowp = col + (rok ? iy : 0) * (14 * ES11);
+                        const unsigned char* rowp = col + (rok ? iy : 0) * (7 * ES2);
 #pragma unroll
                         for (int pp = 0; pp < 7; ++pp) {
-                            const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES11);
-                            const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES11);
-                            P[r][pp] = rok ? (lo | (hi << 16)) : 0u;
+                            const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
+                            P[r][pp] = rok ? v : 0u;
                         }
                     }
 #pragma unroll
@@ -2412,12 +2413,13 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     static_assert(ST == 1 || (ST == 2 && KSD == 5), "stride 2 is the 5x5 block 11");
     constexpr int HW = 196, CH = 96, NCHK = CE / CH, NPF = 13, NTILE = 6 * NPF;
     constexpr int HWO = ST == 1 ? 196 : 49, NBAND = ST == 1 ? 5 : 4;
-    constexpr int ES = CH * 2 + 16;         // bytes per E row
+    constexpr int ES2 = 416;                // bytes per row of E2[98 pixel pairs][96 channels] (one dword = pixels 2p, 2p+1 of a
+                                            // channel); 104 dwords: the four lane quarters of a store land in disjoint banks
     constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2;
     static_assert(CE % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* E = smem;
-    float* pband = reinterpret_cast<float*>(E + HW * ES);   // [5][96]
+    float* pband = reinterpret_cast<float*>(E + 98 * ES2);   // [5][96]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
@@ -2475,21 +2477,25 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 #pragma unroll
                     for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((nfg + 1) * CKS + ks) * 64 + lane) * 16));
                 }
-                const f4 bv = gload<f4>(bexp, (unsigned)(16 * nfg + 4 * q) * 4u);
+                // un-swapped MFMA (pixels = rows, channels = columns): lane (m, q) gets channel 16 nf + m of pixels
+                // 16 pf + 4q .. +3 = two ready-made pixel pairs (same dot products, same k order as the swapped form)
+                const float bs = gload<float>(bexp, (unsigned)(16 * nfg + m) * 4u);
+                const f4 bv = {bs, bs, bs, bs};
                 f4 acc[2] = {bv, bv};
 #pragma unroll
                 for (int ks = 0; ks < CKS; ++ks) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[0][ks], acc[0], 0, 0, 0);
-                    if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[1][ks], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0][ks], wc[ks], acc[0], 0, 0, 0);
+                    if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[1][ks], wc[ks], acc[1], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int pix = 16 * (pf0 + i) + m;
-                    if (i < npf && pix < HW) {
-                        h4 o;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[i][j]);
-                        *reinterpret_cast<h4*>(E + pix * ES + (16 * nf + 4 * q) * 2) = o;
+                    const int pix0 = 16 * (pf0 + i) + 4 * q;
+                    if (i < npf && pix0 < HW) {
+                        h2 p0 = {(_Float16)silu_scaled(acc[i][0]), (_Float16)silu_scaled(acc[i][1])};
+                        h2 p1 = {(_Float16)silu_scaled(acc[i][2]), (_Float16)silu_scaled(acc[i][3])};
+                        unsigned char* dst = E + (pix0 >> 1) * ES2 + (16 * nf + m) * 4;
+                        *reinterpret_cast<h2*>(dst) = p0;
+                        *reinterpret_cast<h2*>(dst + ES2) = p1;
                     }
                 }
             }
@@ -2499,18 +2505,17 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         float psum = 0.f;
         {
             constexpr int NR = ST == 1 ? 3 + 2 * R : 7;   // input rows of a band (3 output rows; stride 2: 2 output rows)
-            const unsigned char* col = E + 2 * cd;
+            const unsigned char* col = E + 4 * cd;
             uint32_t P[NR][7];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int iy = (ST == 1 ? rb - R : 4 * band - 1) + r;
                 const bool rok = iy >= 0 && iy < 14;
-                const unsigned char* rowp = col + (rok ? iy : 0) * (14 * ES);
+                const unsigned char* rowp = col + (rok ? iy : 0) * (7 * ES2);
 #pragma unroll
                 for (int pp = 0; pp < 7; ++pp) {
-                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES);
-                    const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES);
-                    P[r][pp] = rok ? (lo | (hi << 16)) : 0u;
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
+                    P[r][pp] = rok ? v : 0u;
                 }
             }
             _Float16* dg = a.D + (size_t)b * HWO * CE + chunk * CH + cd;
@@ -3763,7 +3768,7 @@ int proj_patch_has(int K, int N, int HW, int res)
 template <int CKS, int KSD, int CE, int ST = 1>
 static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
 {
-    const int lds = 196 * (96 * 2 + 16) + 5 * 96 * 4;
+    const int lds = 98 * 416 + 5 * 96 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE, ST>),
