@@ -2614,10 +2614,12 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
 {
-    constexpr int NPOS = 17 * 57, NPF = (NPOS + 15) / 16, ES = 80;   // 969 positions, 61 fragments, bytes per E row
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // The window is enumerated with 58 columns (29 pixel pairs; the 58th column is one more real pixel, or zero past the image):
+    // a 4-position group of the un-swapped expand MFMA is two whole pairs, stored as E2[17 x 29 pairs][32 channels] dwords.
+    constexpr int WC = 58, NPOS = 17 * WC, NPF = (NPOS + 15) / 16, ES2 = 160;   // 986 positions, 62 fragments, bytes per pair row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // (40 dwords: the lane quarters of a store hit disjoint banks)
     unsigned char* E = smem;
-    float* pred = reinterpret_cast<float*>(smem + NPF * 16 * ES);    // [16][32] pool partials
+    float* pred = reinterpret_cast<float*>(smem + NPF * 8 * ES2);    // [16][32] pool partials
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
@@ -2627,28 +2629,35 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
     // ---------------- expand (with block 0's gate + project in front) ----------------
     {
         u4v xr[8];
-        bool ok[8];
-        int pos[8];
+        bool okp[8][2];   // validity of this lane's two OUTPUT pairs (positions 16 pf + 4q .. +3): inside the window and the image
+        int ppair[8];     // index of the first of them
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pf = wave + 8 * i;
             const int p = 16 * pf + m;
-            const int r = p / 57, c = p - r * 57;
+            const int r = p / WC, c = p - r * WC;
             const int iy = iy0 + r, ix = ix0 + c;
-            ok[i] = pf < NPF && p < NPOS && iy < 112 && ix < 112;
-            pos[i] = p;
-            xr[i] = gload<u4v>(xg, (unsigned)((((ok[i] ? iy : 0) * 112 + (ok[i] ? ix : 0)) * 32 + 8 * q) * 2));
+            const bool ok = pf < NPF && p < NPOS && iy < 112 && ix < 112;
+            xr[i] = gload<u4v>(xg, (unsigned)((((ok ? iy : 0) * 112 + (ok ? ix : 0)) * 32 + 8 * q) * 2));
+            const int p0 = 16 * pf + 4 * q;
+            ppair[i] = p0 >> 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pp = p0 + 2 * h;                 // even position: the pair (pp, pp+1) lies in one row
+                const int pr = pp / WC, pc = pp - pr * WC;
+                okp[i][h] = pf < NPF && pp < NPOS && iy0 + pr < 112 && ix0 + pc < 112;   // 112 is even: a pair is in or out as a whole
+            }
         }
         const h8 wpre = *reinterpret_cast<const h8*>(a.pre_w + lane * 8);
         const f4 bpre = *reinterpret_cast<const f4*>(a.pre_b + 4 * q);
         const f4 g0 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q);
         const f4 g1 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q + 4);
         h8 wexp[2];
-        f4 bexp[2];
+        float bexp[2];
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
             wexp[nf] = *reinterpret_cast<const h8*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));
-            bexp[nf] = *reinterpret_cast<const f4*>(a.bexp + chunk * 32 + 16 * nf + 4 * q);
+            bexp[nf] = a.bexp[chunk * 32 + 16 * nf + m];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -2661,11 +2670,15 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
             for (int j = 0; j < 4; ++j) xb[j] = (_Float16)x1[j];   // block 0's output, rounded as the separate path stores it
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
-                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wexp[nf], xb, bexp[nf], 0, 0, 0);
-                h4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = ok[i] ? (_Float16)silu_scaled(acc[j]) : (_Float16)0.0f;
-                *reinterpret_cast<h4*>(E + pos[i] * ES + (16 * nf + 4 * q) * 2) = o;
+                // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
+                const f4 bv = {bexp[nf], bexp[nf], bexp[nf], bexp[nf]};
+                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb, wexp[nf], bv, 0, 0, 0);
+                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
+                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+                const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
+                unsigned char* dst = E + ppair[i] * ES2 + (16 * nf + m) * 4;
+                *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
+                *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
             }
         }
     }
@@ -2684,17 +2697,13 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
             wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
         }
         const float dbias = a.bdw[cg];
-        const unsigned char* col = E + 2 * c;
+        const unsigned char* col = E + 4 * c;
         uint32_t P[3][15];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const unsigned char* rowp = col + ((2 * orow + ky) * 57 + 28 * half) * ES;
+            const unsigned char* rowp = col + ((2 * orow + ky) * 29 + 14 * half) * ES2;
 #pragma unroll
-            for (int pp = 0; pp < 15; ++pp) {
-                const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * ES);
-                const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * ES);
-                P[ky][pp] = lo | (hi << 16);
-            }
+            for (int pp = 0; pp < 15; ++pp) P[ky][pp] = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
         }
         float acc[14];
 #pragma unroll
@@ -3798,7 +3807,7 @@ int launch_mid14(const Mid14Args& a, hipStream_t st)
 int launch_mb1(const Mb1Args& a, hipStream_t st)
 {
     if (a.B < 1) return -15;
-    const int lds = 61 * 16 * 80 + 16 * 32 * 4;
+    const int lds = 62 * 8 * 160 + 16 * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
