@@ -2397,9 +2397,10 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 // workgroups that each re-load the block input and pay their own load/barrier skeleton; here the input X[196][Cin]
 // is loaded once into LDS and the workgroup walks the expanded channels in chunks of 96:
 //   expand   78 (16-channel x 16-pixel) tiles per chunk, dealt round-robin to the 8 waves; swapped MFMA, weight
-//            fragments from L2 one tile ahead, pixel fragments from LDS; silu -> E[196][96] fp16 in LDS;
-//   dw       thread = (channel, band of 3 output rows): the 7 input rows it needs become 7x7 pixel-pair dwords in
-//            registers (zero outside the image), taps on v_dot2c exactly as in tail7_kernel, the 14 outputs of a row
+//            fragments from L2 one tile ahead, pixel fragments in registers; un-swapped (pixels = rows), so a lane holds 4
+//            consecutive pixels of one channel: silu -> two pixel-pair dwords of E2[98 pairs][96 channels] in LDS;
+//   dw       thread = (channel, band of 3 output rows): the 7 input rows it needs are 7x7 pixel-pair dwords (one ds_read_b32
+//            each) in registers (zero outside the image), taps on v_dot2c exactly as in tail7_kernel, the 14 outputs of a row
 //            advance together; silu; fp16 straight to the depthwise output tensor in HBM (lanes = consecutive
 //            channels: 128-byte segments); pool sums per band -> LDS -> one value per channel.
 // Output: D[B][196][CE] and pool[B][CE] -- what proj_patch_kernel consumes.
@@ -2606,9 +2607,10 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 // tile of 8 rows x 28 columns, chunk of 32 expanded channels); its input window is 17 x 57 positions.
 //   expand   wave w owns the 16-position fragments w, w+8, ...: block 0's depthwise output is read straight into
 //            registers (all loads first: one round trip), scaled by block 0's gate, projected by ONE MFMA (K-permuted
-//            expand weights, as in mbconv_a_kernel PRE), expanded by two MFMAs, silu -> E[976][32] fp16 in LDS; positions
-//            outside the image are written as zeros (padding lives in the expanded domain).
-//   dw       thread = (channel, output row, half of the 28 columns): 3 input rows x 15 pixel pairs in registers,
+//            expand weights, as in mbconv_a_kernel PRE), expanded by two un-swapped MFMAs (a lane gets 4 consecutive
+//            positions of one channel), silu -> pixel-pair dwords E2[17 x 29 pairs][32] in LDS; positions outside the image
+//            are written as zeros (padding lives in the expanded domain).
+//   dw       thread = (channel, output row, half of the 28 columns): 3 input rows x 15 pixel pairs (one ds_read_b32 each) in registers,
 //            two v_dot2c per kernel row and output ((k0,k1) on pair j, (k2,0) on pair j+1), silu, fp16 to HBM,
 //            pool sums through LDS -> pool[patch][tile][96].
 // ---------------------------------------------------------------------------------------------
