@@ -2749,14 +2749,16 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
 template <int KSD, int CKS, int CE, int HIMG>
 __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
 {
-    constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2, NROWS = 14 + 2 * R, CH = 48, ES = CH * 2 + 16;
+    constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2, NROWS = 14 + 2 * R, CH = 48;
+    constexpr int ES2 = 224;                              // bytes per row of E2[window pixel pairs][48 channels] (56 dwords: the
+                                                          // four lane quarters of a store hit disjoint banks)
     constexpr int WW = HIMG == 28 ? 28 : 30;              // window columns (even aligned)
     constexpr int NPOS = NROWS * WW, NPF = (NPOS + 15) / 16;
     static_assert(NPF <= 32, "four fragments per wave");
     constexpr int TX = HIMG / 28, NR = 3 + 2 * R;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* E = smem;                                            // [NPF*16][ES]
-    float* pred = reinterpret_cast<float*>(smem + NPF * 16 * ES);       // [10][48]
+    unsigned char* E = smem;                                            // [NPF*8][ES2]
+    float* pred = reinterpret_cast<float*>(smem + NPF * 8 * ES2);       // [10][48]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
@@ -2769,14 +2771,21 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
     // ---------------- expand ----------------
     {
         u4v xr[4][CKS];
-        bool ok[4];
+        bool okp[4][2];   // validity of this lane's two output pairs (positions 16 pf + 4q .. +3): window and image
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 16 * (wave + 8 * i) + m;
             const int r = p / WW, c = p - r * WW;
             const int iy = oy0 - R + r, ix = wx0 + c;
-            ok[i] = p < NPOS && iy >= 0 && iy < HIMG && ix < HIMG;
-            const int row = ok[i] ? iy * HIMG + ix : 0;
+            const bool ok = p < NPOS && iy >= 0 && iy < HIMG && ix < HIMG;
+            const int row = ok ? iy * HIMG + ix : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pp = 16 * (wave + 8 * i) + 4 * q + 2 * h;      // even: the pair lies in one window row, and is in or out
+                const int pr = pp / WW, pc = pp - pr * WW;               // of the image as a whole (wx0 and HIMG are even)
+                const int py = oy0 - R + pr;
+                okp[i][h] = pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG;
+            }
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
                 const int kk = 32 * ks + 8 * q;
@@ -2784,13 +2793,13 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
             }
         }
         h8 wa[3][CKS];
-        f4 ba[3];
+        float ba[3];
 #pragma unroll
         for (int nf = 0; nf < 3; ++nf) {
             const int nfg = 3 * chunk + nf;
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
-            ba[nf] = *reinterpret_cast<const f4*>(a.bexp + 16 * nfg + 4 * q);
+            ba[nf] = a.bexp[16 * nfg + m];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -2802,16 +2811,19 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                 const u4v mk = {xr[i][ks].x & keep, xr[i][ks].y & keep, xr[i][ks].z & keep, xr[i][ks].w & keep};
                 xb[ks] = *reinterpret_cast<const h8*>(&mk);
             }
-            const int p = 16 * (wave + 8 * i) + m;
+            const int pair0 = 8 * (wave + 8 * i) + 2 * q;
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) {
-                f4 acc = ba[nf];
+                // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
+                f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[nf][ks], xb[ks], acc, 0, 0, 0);
-                h4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = ok[i] ? (_Float16)silu_scaled(acc[j]) : (_Float16)0.0f;
-                *reinterpret_cast<h4*>(E + p * ES + (16 * nf + 4 * q) * 2) = o;
+                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
+                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
+                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+                const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
+                unsigned char* dst = E + pair0 * ES2 + (16 * nf + m) * 4;
+                *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
+                *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
             }
         }
     }
@@ -2830,20 +2842,18 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
         // window pair columns of this half: local pair l (0..8) <-> window pair (cbase/2 - 1 + l); cbase is even
         const int cbase = ox0 + 14 * half - wx0;
         const int pb = (cbase >> 1) - 1;
-        const unsigned char* col = E + 2 * c;
+        const unsigned char* col = E + 4 * c;
         uint32_t P[NR][9];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int wr = rb + r < NROWS ? rb + r : NROWS - 1;     // (band 4 has two output rows: its last window row is unused)
-            const unsigned char* rowp = col + (wr * WW) * ES;
+            const unsigned char* rowp = col + (wr * (WW / 2)) * ES2;
 #pragma unroll
             for (int l = 0; l < 9; ++l) {
                 const int wp = pb + l;
                 const bool pok = wp >= 0 && wp < WW / 2;
-                const int wpc = pok ? wp : 0;
-                const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * wpc) * ES);
-                const uint32_t hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * wpc + 1) * ES);
-                P[r][l] = pok ? (lo | (hi << 16)) : 0u;
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (pok ? wp : 0) * ES2);
+                P[r][l] = pok ? v : 0u;
             }
         }
         float psum = 0.f;

@@ -449,7 +449,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
     const char* mbt_env = getenv("MMC_MBT");
-    const bool mbt_enabled = fuse_enabled && (mbt_env && mbt_env[0] == '1');
+    const bool mbt_enabled = fuse_enabled && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
     const char* tail_env = getenv("MMC_TAIL");
     const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
