@@ -125,6 +125,7 @@ struct MbtArgs {
     _Float16* D;              // [B][H][H][Ce]
     float* pool;              // [B][tiles][Ce]
     int B, H, Cin, Ce, ks;
+    int stride;               // 1 (b2, b4: D is [B][H][H][Ce]) or 2 (b3, b5: D is [B][H/2][H/2][Ce], mbt2_kernel)
 };
 int launch_mbt(const MbtArgs& a, hipStream_t st);
 

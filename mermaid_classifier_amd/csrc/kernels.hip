@@ -2905,6 +2905,151 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// mbt2_kernel: the same recipe for the STRIDE-2 blocks at 56x56 and 28x28 (b3: 5x5, 24 -> 144; b5: 3x3, 40 -> 240).
+// One workgroup (512 threads) = (patch, output tile of 7 rows x 14 columns, chunk of 48 expanded channels).  The tile's
+// input window (12 + KSD rows, 32 or 30 columns starting on an even column) is expanded un-swapped into pixel-pair dwords
+// E2[window pairs][48] in LDS (zeros outside the image); a depthwise thread = (channel, output row) holds its KSD rows x
+// 16 pixel pairs in registers and runs v_dot2c: output x reads the pairs pbase + x + ip with the tap pairs (0,k0), (k1,k2),
+// (k3,k4) for 5x5 (TF-same pad 1) and (k0,k1), (k2,0) for 3x3 (pad 0).  Output D[B][H/2][H/2][CE], pool[B][tiles][CE].
+// ---------------------------------------------------------------------------------------------
+template <int KSD, int CKS, int CE, int HIMG>
+__global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
+{
+    constexpr int PADB = KSD == 5 ? 1 : 0, NIP = KSD == 5 ? 3 : 2, NROWS = 12 + KSD, CH = 48, ES2 = 224;
+    constexpr int WW = KSD == 5 ? 32 : 30, NPOS = NROWS * WW, NPF = (NPOS + 15) / 16, NS = (NPF + 7) / 8;
+    constexpr int HOUT = HIMG / 2, TX = HOUT / 14, NPR = KSD == 5 ? 16 : 15;   // pixel pairs per window row a thread needs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;                                            // [NS*8*8][ES2]
+    float* pred = reinterpret_cast<float*>(smem + NS * 64 * ES2);       // [7][48]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int ty = tile / TX, tx = tile - ty * TX;
+    const int oy0 = 7 * ty, ox0 = 14 * tx;
+    const int wy0 = 2 * oy0 - PADB;                                     // may be -1: that row is padding
+    int wx0 = (2 * ox0 - PADB) & ~1;
+    wx0 = wx0 < 0 ? 0 : wx0;
+    const int pbase = (2 * ox0 - PADB - wx0 - (KSD == 5 ? 1 : 0)) >> 1;   // window pair of output column 0's first tap pair (-1: left padding)
+    const int Cin = a.Cin;
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HIMG * HIMG * Cin;
+    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    // ---------------- expand ----------------
+    {
+        u4v xr[NS][CKS];
+        bool okp[NS][2];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int p = 16 * (wave + 8 * i) + m;
+            const int r = p / WW, c = p - r * WW;
+            const int iy = wy0 + r, ix = wx0 + c;
+            const bool ok = p < NPOS && iy >= 0 && iy < HIMG && ix < HIMG;
+            const int row = ok ? iy * HIMG + ix : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pp = 16 * (wave + 8 * i) + 4 * q + 2 * h;
+                const int pr = pp / WW, pc = pp - pr * WW;
+                const int py = wy0 + pr;
+                okp[i][h] = pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG;
+            }
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const int kk = 32 * ks + 8 * q;
+                xr[i][ks] = gload<u4v>(xg, (unsigned)((row * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
+            }
+        }
+        h8 wa[3][CKS];
+        float ba[3];
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) {
+            const int nfg = 3 * chunk + nf;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
+            ba[nf] = a.bexp[16 * nfg + m];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (wave + 8 * i >= NPF) continue;   // wave-uniform
+            h8 xb[CKS];
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const uint32_t keep = (32 * ks + 8 * q < Cin) ? 0xffffffffu : 0u;
+                const u4v mk = {xr[i][ks].x & keep, xr[i][ks].y & keep, xr[i][ks].z & keep, xr[i][ks].w & keep};
+                xb[ks] = *reinterpret_cast<const h8*>(&mk);
+            }
+            const int pair0 = 8 * (wave + 8 * i) + 2 * q;
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
+                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
+                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+                const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
+                unsigned char* dst = E + pair0 * ES2 + (16 * nf + m) * 4;
+                *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
+                *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
+            }
+        }
+    }
+    T7_BAR();
+    // ---------------- depthwise, stride 2 ----------------
+    {
+        const int c = tid % CH, orow = tid / CH;            // orow 0..6 work, 7..10 idle
+        const bool dw_thr = orow < 7;
+        const int orc = dw_thr ? orow : 0;
+        const int cg = chunk * CH + c;
+        uint32_t raw[15];
+#pragma unroll
+        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg];
+        const float dbias = a.bdw[cg];
+        const unsigned char* col = E + 4 * c;
+        uint32_t P[KSD][NPR];
+#pragma unroll
+        for (int ky = 0; ky < KSD; ++ky) {
+            const unsigned char* rowp = col + ((2 * orc + ky) * (WW / 2)) * ES2;
+#pragma unroll
+            for (int l = 0; l < NPR; ++l) {
+                const int wp = pbase + l;
+                const bool pok = wp >= 0 && wp < WW / 2;
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (pok ? wp : 0) * ES2);
+                P[ky][l] = pok ? v : 0u;
+            }
+        }
+        float acc[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) acc[j] = dbias;
+#pragma unroll
+        for (int ky = 0; ky < KSD; ++ky) {
+            const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+            uint32_t wq[3];
+            if (KSD == 5) { wq[0] = r0 << 16; wq[1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[2] = __builtin_amdgcn_alignbit(r2, r1, 16); }
+            else { wq[0] = r0; wq[1] = r1; wq[2] = 0u; }
+#pragma unroll
+            for (int ip = 0; ip < NIP; ++ip)
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ip]), acc[j], false);
+        }
+        float psum = 0.f;
+        _Float16* dg = a.D + (((size_t)b * HOUT + oy0 + orc) * HOUT + ox0) * CE + cg;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const float y = silu_scaled(acc[j]);
+            psum += y;
+            if (dw_thr) dg[(size_t)j * CE] = (_Float16)y;
+        }
+        if (dw_thr) pred[orow * CH + c] = psum;
+    }
+    T7_BAR();
+    if (tid < CH) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 7; ++w) s += pred[w * CH + tid];
+        a.pool[((size_t)b * gridDim.x + tile) * CE + chunk * CH + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
 // project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
@@ -3848,9 +3993,31 @@ static int launch_mbt_t(const MbtArgs& a, hipStream_t st)
     return 0;
 }
 
+template <int KSD, int CKS, int CE, int HIMG>
+static int launch_mbt2_t(const MbtArgs& a, hipStream_t st)
+{
+    constexpr int NROWS = 12 + KSD, WW = KSD == 5 ? 32 : 30, NPF = (NROWS * WW + 15) / 16, NS = (NPF + 7) / 8, HOUT = HIMG / 2;
+    const int lds = NS * 64 * 224 + 7 * 48 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbt2_kernel<KSD, CKS, CE, HIMG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mbt2_kernel<KSD, CKS, CE, HIMG>), dim3((HOUT / 7) * (HOUT / 14), CE / 48, a.B), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_mbt(const MbtArgs& a, hipStream_t st)
 {
     if (a.B < 1) return -16;
+    if (a.stride == 2) {
+        if (a.H == 56 && a.ks == 5 && a.Cin == 24 && a.Ce == 144) return launch_mbt2_t<5, 1, 144, 56>(a, st);   // b3
+        if (a.H == 28 && a.ks == 3 && a.Cin == 40 && a.Ce == 240) return launch_mbt2_t<3, 2, 240, 28>(a, st);   // b5
+        return -5;
+    }
     if (a.H == 56 && a.ks == 3 && a.Cin == 24 && a.Ce == 144) return launch_mbt_t<3, 1, 144, 56>(a, st);   // b2
     if (a.H == 28 && a.ks == 5 && a.Cin == 40 && a.Ce == 240) return launch_mbt_t<5, 2, 240, 28>(a, st);   // b4
     return -5;

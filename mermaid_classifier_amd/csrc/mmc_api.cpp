@@ -246,6 +246,7 @@ struct mmc_backbone {
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
     bool fuse_b0b1 = false;
     bool mbt = false;                // blocks 2 and 4 on mbt_kernel (tiled, window-in-registers depthwise)
+    bool mbt2 = false;               // ... and the stride-2 blocks 3 and 5 on mbt2_kernel
     bool mb1 = false;                // block 1 on mb1_kernel (window-in-registers depthwise) instead of mbconv_a PRE
     bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
     int mid14_last = 8;              // ... for blocks 6..mid14_last
@@ -451,6 +452,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const char* mbt_env = getenv("MMC_MBT");
     const bool mbt_enabled = fuse_enabled && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
+    { const char* e = getenv("MMC_MBT2"); bb->mbt2 = mbt_enabled && !(e && e[0] == '0'); }
     const char* tail_env = getenv("MMC_TAIL");
     const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
     int H = IMG / 2;
@@ -489,7 +491,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if ((tail_enabled && i >= 11 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && (i == 2 || i == 4))) {
+            if ((tail_enabled && i >= 11 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && i >= 2 && i <= 5)) {
                 // taps of tail7_kernel / mid14_kernel / mbt_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
@@ -933,11 +935,11 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             STEP("stem+b0.dw", "stem_dw", launch_stem_dw(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, B.dw_w, B.dw_b,
                                                           bb->fuse_b0b1 ? y : ws.dwbuf, ws.pool_part, n, st));
             nparts = 49;
-        } else if (B.fused && bb->mbt && (i == 2 || i == 4) && B.t_dwp && B.exp_frag) {
+        } else if (B.fused && B.t_dwp && B.exp_frag && ((bb->mbt && (i == 2 || i == 4)) || (bb->mbt2 && (i == 3 || i == 5)))) {
             MbtArgs ta{};
             ta.X = x; ta.wexp = B.exp_frag; ta.bexp = B.expand.b; ta.dwp = B.t_dwp; ta.bdw = B.dw_b; ta.D = ws.dwbuf;
-            ta.pool = ws.pool_part; ta.B = n; ta.H = B.H; ta.Cin = B.d.cin; ta.Ce = B.ce; ta.ks = B.d.k;
-            nparts = (B.H / 14) * (B.H / 28);
+            ta.pool = ws.pool_part; ta.B = n; ta.H = B.H; ta.Cin = B.d.cin; ta.Ce = B.ce; ta.ks = B.d.k; ta.stride = B.d.s;
+            nparts = B.d.s == 2 ? (B.Ho / 7) * (B.Ho / 14) : (B.H / 14) * (B.H / 28);
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             STEP(nm, "mbt", launch_mbt(ta, st));
         } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
