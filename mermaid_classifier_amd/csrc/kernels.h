@@ -128,6 +128,7 @@ struct MbtArgs {
     int stride;               // 1 (b2, b4: D is [B][H][H][Ce]) or 2 (b3, b5: D is [B][H/2][H/2][Ce], mbt2_kernel)
 };
 int launch_mbt(const MbtArgs& a, hipStream_t st);
+int mbt_has(int H, int ks, int stride, int Cin, int Ce);   // 1 when launch_mbt has an instantiation for this layer
 
 // Front half of a 14x14 MBConv block for one patch per workgroup (mid14_kernel)
 struct Mid14Args {

@@ -4016,9 +4016,23 @@ int launch_mbt(const MbtArgs& a, hipStream_t st)
     if (a.stride == 2) {
         if (a.H == 56 && a.ks == 5 && a.Cin == 24 && a.Ce == 144) return launch_mbt2_t<5, 1, 144, 56>(a, st);   // b3
         if (a.H == 28 && a.ks == 3 && a.Cin == 40 && a.Ce == 240) return launch_mbt2_t<3, 2, 240, 28>(a, st);   // b5
+        if (a.H == 56 && a.ks == 5 && a.Cin == 32 && a.Ce == 192) return launch_mbt2_t<5, 1, 192, 56>(a, st);   // B4 b6
+        if (a.H == 28 && a.ks == 3 && a.Cin == 56 && a.Ce == 336) return launch_mbt2_t<3, 2, 336, 28>(a, st);   // B4 b10
         return -5;
     }
     if (a.H == 56 && a.ks == 3 && a.Cin == 24 && a.Ce == 144) return launch_mbt_t<3, 1, 144, 56>(a, st);   // b2
     if (a.H == 28 && a.ks == 5 && a.Cin == 40 && a.Ce == 240) return launch_mbt_t<5, 2, 240, 28>(a, st);   // b4
+    if (a.H == 56 && a.ks == 3 && a.Cin == 32 && a.Ce == 192) return launch_mbt_t<3, 1, 192, 56>(a, st);   // B4 b3-b5
+    if (a.H == 28 && a.ks == 5 && a.Cin == 56 && a.Ce == 336) return launch_mbt_t<5, 2, 336, 28>(a, st);   // B4 b7-b9
     return -5;
+}
+
+// the layer shapes launch_mbt has an instantiation for
+int mbt_has(int H, int ks, int stride, int Cin, int Ce)
+{
+    static const int T[][5] = {{56, 3, 1, 24, 144}, {28, 5, 1, 40, 240}, {56, 5, 2, 24, 144}, {28, 3, 2, 40, 240},
+                               {56, 3, 1, 32, 192}, {28, 5, 1, 56, 336}, {56, 5, 2, 32, 192}, {28, 3, 2, 56, 336}};
+    for (auto& t : T)
+        if (t[0] == H && t[1] == ks && t[2] == stride && t[3] == Cin && t[4] == Ce) return 1;
+    return 0;
 }

@@ -433,6 +433,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     }
     // ---- blocks ----
     const char* fuse_env = getenv("MMC_FUSE");
+    const bool fuse_generic_early = !is_b0 && !(fuse_env && fuse_env[0] == '0');   // (= fuse_generic, needed before its definition)
     const bool fuse_enabled = is_b0 && !(fuse_env && fuse_env[0] == '0');   // the fused kernels are shaped for B0's layers
     const char* dot2_env = getenv("MMC_MB_DOT2");
     const bool dot2_enabled = !(dot2_env && dot2_env[0] == '0');
@@ -450,7 +451,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
     const char* mbt_env = getenv("MMC_MBT");
-    const bool mbt_enabled = fuse_enabled && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
+    const bool mbt_enabled = (fuse_enabled || fuse_generic_early) && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
     { const char* e = getenv("MMC_MBT2"); bb->mbt2 = mbt_enabled && !(e && e[0] == '0'); }
     const char* tail_env = getenv("MMC_TAIL");
@@ -491,7 +492,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<float> db(B.ce);
             for (int c = 0; c < B.ce; ++c) db[c] = (float)(b[c] * LOG2E);
             TRY_OR_FREE(dev_upload(bb, &B.dw_b, db));
-            if ((tail_enabled && i >= 11 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && i >= 2 && i <= 5)) {
+            if ((tail_enabled && i >= 11 && i <= 15) || (mid14_enabled && i >= 6 && i <= 11) || (mbt_enabled && mbt_has(H, B.d.k, B.d.s, B.d.cin, B.ce))) {
                 // taps of tail7_kernel / mid14_kernel / mbt_kernel as fp16 pairs: kernel row ky = (k0,k1), (k2,k3), (k4,0); the kernel derives the
                 // odd-output pairs by shifts, giving the same values as mbconv_d_kernel's wl2 table
                 std::vector<uint32_t> dp((size_t)15 * B.ce, 0u);
@@ -935,7 +936,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             STEP("stem+b0.dw", "stem_dw", launch_stem_dw(patches_dev, bb->stem_w, bb->stem_b, bb->stem_pad, B.dw_w, B.dw_b,
                                                           bb->fuse_b0b1 ? y : ws.dwbuf, ws.pool_part, n, st));
             nparts = 49;
-        } else if (B.fused && B.t_dwp && B.exp_frag && ((bb->mbt && (i == 2 || i == 4)) || (bb->mbt2 && (i == 3 || i == 5)))) {
+        } else if (B.fused && B.t_dwp && B.exp_frag && (B.d.s == 1 ? bb->mbt : bb->mbt2) && mbt_has(B.H, B.d.k, B.d.s, B.d.cin, B.ce)) {
             MbtArgs ta{};
             ta.X = x; ta.wexp = B.exp_frag; ta.bexp = B.expand.b; ta.dwp = B.t_dwp; ta.bdw = B.dw_b; ta.D = ws.dwbuf;
             ta.pool = ws.pool_part; ta.B = n; ta.H = B.H; ta.Cin = B.d.cin; ta.Ce = B.ce; ta.ks = B.d.k; ta.stride = B.d.s;
