@@ -209,8 +209,9 @@ def main():
             pmc = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
             table = json.loads(pmc.read_text())
             key = dom.split("<")[0]
+            targs = lambda name: [t.strip() for t in name.split("<")[1].split(">")[0].split(",")][:3]   # noqa: E731
             hits = [v for k, v in table.items() if k.split("<")[0].replace("_kernel", "") == key.replace("_kernel", "")
-                    and (("<" not in dom) or k.split("<")[1].split(">")[0].split(",")[:3] == dom.split("<")[1].split(">")[0].split(",")[:3])]
+                    and (("<" not in dom) or ("<" in k and targs(k) == targs(dom)))]
             if hits:
                 traffic = sum(h["read_bytes_per_launch"] + h["write_bytes_per_launch"] for h in hits) / len(hits)
         except Exception:

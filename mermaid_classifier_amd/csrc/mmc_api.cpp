@@ -942,7 +942,9 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             ta.pool = ws.pool_part; ta.B = n; ta.H = B.H; ta.Cin = B.d.cin; ta.Ce = B.ce; ta.ks = B.d.k; ta.stride = B.d.s;
             nparts = B.d.s == 2 ? (B.Ho / 7) * (B.Ho / 14) : (B.H / 14) * (B.H / 28);
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
-            STEP(nm, "mbt", launch_mbt(ta, st));
+            char ml[48];   // the instantiation's template arguments, as rocprofv3 names it
+            snprintf(ml, sizeof ml, "%s<%d,%d,%d,%d>", B.d.s == 2 ? "mbt2" : "mbt", B.d.k, (B.d.cin + 31) / 32, B.ce, B.H);
+            STEP(nm, ml, launch_mbt(ta, st));
         } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
             Mid14Args ma{};
             ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
@@ -951,7 +953,9 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             ma.stride = B.d.s;
             nparts = 1;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
-            STEP(nm, "mid14", launch_mid14(ma, st));
+            char ml[48];
+            snprintf(ml, sizeof ml, "mid14<%d,%d,%d,%d>", (B.d.cin + 31) / 32, B.d.k, B.ce, B.d.s);
+            STEP(nm, ml, launch_mid14(ma, st));
         } else if (B.fused) {
             MbArgs a{};
             a.X = x; a.Wexp = B.exp_nat; a.bexp = B.expand.b; a.Wdw = B.dw_w; a.bdw = B.dw_b; a.out = ws.dwbuf;
