@@ -90,6 +90,12 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
+    # The JSON line must be the only thing on stdout: RCCL prints a five-line version banner to fd 1 when a communicator is
+    # created (N > 1).  Keep the real stdout aside for the JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -153,6 +159,11 @@ def main():
                 pending[i].wait()
                 pending[i] = None
 
+    # Engine initialisation, before the W warm-up steps: the library captures a pass into a HIP graph the third time the same
+    # buffers come in (mmc_api.cpp run_pass) -- a one-off cost of a few ms that belongs to set-up like the weights upload, so
+    # that a small W cannot push it into the timed region.
+    for _ in range(3):
+        step()
     for _ in range(args.warmup):
         step()
     drain()
@@ -240,7 +251,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd)
         kernels = sorted(((k, v[0] / args.profile_passes) for k, v in per_kernel.items()), key=lambda kv: -kv[1])
         print("# per-kernel ms/step (HIP events): " + ", ".join(f"{k}={v:.3f}" for k, v in kernels), file=sys.stderr)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
