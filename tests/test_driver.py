@@ -132,6 +132,37 @@ def test_driver_on_gpu_matches_direct_extraction(tmp_path, synth_sd):
 
 
 @pytest.mark.gpu
+def test_batched_extractor_sparse_points_many_flushes_bitwise(synth_sd):
+    """Config-3 geometry in the regime the reference's data lives in: big decoded images, few points each -> the patches are
+    cut on the host into pinned slots and uploaded on the copy stream, two patch buffers alternate, results are collected per
+    pass through events.  With a 40-patch buffer the 9 images below take seven flushes; an image may span two flushes; one
+    image has no points; one has more points than the buffer.  Every feature row must equal the direct extraction of the
+    oracle's crop, bit for bit, in rowcols order."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from mermaid_classifier_amd.pipeline import BatchedExtractor
+    from oracle import pyspacer_ref
+    rng = np.random.default_rng(8)
+    base = [rng.integers(0, 255, (2900, 3000, 3), dtype=np.uint8) for _ in range(2)]     # 26 MB: <= 28 points take the host cut
+    images = [base[i % 2] for i in range(9)]
+    counts = [25, 25, 0, 13, 25, 47, 1, 25, 25]                                          # 47 > 40: spans flushes
+    rcs = [[(int(rng.integers(0, 2900)), int(rng.integers(0, 3000))) for _ in range(n)] for n in counts]
+    rcs[0][:4] = [(0, 0), (2899, 2999), (0, 2999), (2899, 0)]                            # corners: reflect padding
+    bb = Backbone(synth_sd, device=0, max_batch=32)
+    try:
+        bx = BatchedExtractor(bb, batch_patches=40)
+        got = bx.extract_images(images, rcs)
+        again = bx.extract_images(images, rcs)                                           # buffers / events are reused across calls
+        assert [g.shape for g in got] == [(n, 1280) for n in counts]
+        for im, rc, g, g2 in zip(images, rcs, got, again):
+            assert np.array_equal(g, g2)
+            if rc:
+                want = bb.extract(pyspacer_ref.crop_patches(im, rc))
+                assert np.array_equal(g, want)
+    finally:
+        bb.close()
+
+
+@pytest.mark.gpu
 def test_config3_chain_driver_to_npy_to_labels(tmp_path, synth_sd, oracle_net):
     """BASELINE config 3 end to end, in miniature: images x 25 points (the 5x5 grid geometry of the reference's
     docs/pyspacer/0032dba6_points.csv, scaled) -> driver (GPU crop, cross-image batches) -> .featurevector files ->
