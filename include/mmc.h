@@ -144,6 +144,10 @@ void mmc_trainer_destroy(mmc_trainer* t);
  * Synchronises `hip_stream` before returning. */
 int mmc_trainer_partial_fit(mmc_trainer* t, const float* X, const int32_t* y, int64_t n, int batch_size, double* avg_loss,
                             void* hip_stream);
+/* The same with the visiting order applied on the device: X / y in their natural order plus `order` (n int64 row indices:
+ * position i of the pass visits row order[i]); NULL order = mmc_trainer_partial_fit.  Needs dims[0] % 4 == 0. */
+int mmc_trainer_partial_fit_ordered(mmc_trainer* t, const float* X, const int32_t* y, const int64_t* order, int64_t n,
+                                    int batch_size, double* avg_loss, void* hip_stream);
 /* Current parameters to host buffers shaped like the create-time ones. */
 int mmc_trainer_get_params(mmc_trainer* t, float* const* W, float* const* b);
 /* Adam moments (which = 0: exp_avg, 1: exp_avg_sq) and step count, read (set = 0) or written (set = 1): what the

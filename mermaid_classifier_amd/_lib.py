@@ -22,7 +22,7 @@ SYMBOLS = [
     "mmc_backbone_workspace_bytes", "mmc_backbone_extract", "mmc_backbone_read_activation",
     "mmc_backbone_profile", "mmc_crop_patches",
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
-    "mmc_trainer_create", "mmc_trainer_destroy", "mmc_trainer_partial_fit", "mmc_trainer_get_params", "mmc_trainer_adam_state",
+    "mmc_trainer_create", "mmc_trainer_destroy", "mmc_trainer_partial_fit", "mmc_trainer_partial_fit_ordered", "mmc_trainer_get_params", "mmc_trainer_adam_state",
     "mmc_trainer_logits",
 ]
 
@@ -89,6 +89,8 @@ def _load() -> C.CDLL:
     lib.mmc_trainer_destroy.argtypes = [vp]
     lib.mmc_trainer_partial_fit.restype = i32
     lib.mmc_trainer_partial_fit.argtypes = [vp, vp, vp, i64, i32, C.POINTER(C.c_double), vp]
+    lib.mmc_trainer_partial_fit_ordered.restype = i32
+    lib.mmc_trainer_partial_fit_ordered.argtypes = [vp, vp, vp, vp, i64, i32, C.POINTER(C.c_double), vp]
     lib.mmc_trainer_get_params.restype = i32
     lib.mmc_trainer_get_params.argtypes = [vp, C.POINTER(fp), C.POINTER(fp)]
     lib.mmc_trainer_adam_state.restype = i32

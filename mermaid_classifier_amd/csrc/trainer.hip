@@ -196,6 +196,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// Xo[i][:] = Xn[order[i]][:], yo[i] = yn[order[i]]: the visiting order of a pass applied on the device (one float4 per thread)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ Xn, const int32_t* __restrict__ yn,
+                                                          const int64_t* __restrict__ order, int64_t n, int d4, float* __restrict__ Xo,
+                                                          int32_t* __restrict__ yo)
+{
+    const int64_t i = blockIdx.x;
+    const int64_t src = order[i];
+    const float4* s = reinterpret_cast<const float4*>(Xn + (size_t)src * d4 * 4);
+    float4* d = reinterpret_cast<float4*>(Xo + (size_t)i * d4 * 4);
+    for (int k = threadIdx.x; k < d4; k += 256) d[k] = s[k];
+    if (threadIdx.x == 0) yo[i] = yn[src];
+    (void)n;
+}
+
 template <bool TA, bool TB>
 int launch_tgemm(const float* A, const float* B, float* C, int M, int N, int K, int epi, const float* aux, float scale, hipStream_t st)
 {
@@ -227,7 +241,10 @@ struct mmc_trainer {
     float* cw = nullptr;                                // class weights or null
     float *X = nullptr, *row_loss = nullptr, *partials = nullptr, *losses = nullptr;
     int32_t* y = nullptr;
-    int64_t cap_n = 0;
+    float* Xn = nullptr;            // natural-order staging of a pass (device-side shuffle)
+    int32_t* yn = nullptr;
+    int64_t* order = nullptr;
+    int64_t cap_n = 0, cap_nn = 0;
     int cap_mb = 0, cap_steps = 0;
     float lr = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, alpha = 1e-4f;
     long long t = 0;                                    // Adam step count
@@ -259,6 +276,7 @@ extern "C" void mmc_trainer_destroy(mmc_trainer* t)
     for (size_t l = 1; l < t->H.size(); ++l) hipFree(t->H[l]);
     for (size_t l = 1; l < t->dZ.size(); ++l) hipFree(t->dZ[l]);
     hipFree(t->cw); hipFree(t->X); hipFree(t->row_loss); hipFree(t->partials); hipFree(t->losses); hipFree(t->y);
+    hipFree(t->Xn); hipFree(t->yn); hipFree(t->order);
     delete t;
 }
 
@@ -377,30 +395,51 @@ static int trainer_step(mmc_trainer* t, int64_t start, int mb, float inv_wsum, f
     return 0;
 }
 
-extern "C" int mmc_trainer_partial_fit(mmc_trainer* t, const float* X, const int32_t* y, int64_t n, int batch_size, double* avg_loss,
-                                       void* hip_stream)
+// `order` (n int64 row indices, or NULL = rows are already in visiting order): the shuffle of torch_classifier.py:251-257 applied
+// on the device -- the natural-order matrix is uploaded as it is and a gather kernel builds the visiting order (when the
+// feature width is a multiple of 4; otherwise, and without `order`, the rows are taken as given).
+extern "C" int mmc_trainer_partial_fit_ordered(mmc_trainer* t, const float* X, const int32_t* y, const int64_t* order, int64_t n,
+                                               int batch_size, double* avg_loss, void* hip_stream)
 {
     if (!t) return mmc_fail(MMC_ERR_ARG, "trainer handle is NULL");
     if (!X || !y) return mmc_fail(MMC_ERR_ARG, "X/y is NULL");
     if (n < 1) return mmc_fail(MMC_ERR_ARG, "n = %lld must be positive", (long long)n);
     if (batch_size < 1) return mmc_fail(MMC_ERR_ARG, "batch_size = %d must be positive", batch_size);
-    for (int64_t i = 0; i < n; ++i)
+    if (order && (t->dims[0] & 3)) return mmc_fail(MMC_ERR_ARG, "device-side ordering needs a feature width that is a multiple of 4 (got %d)", t->dims[0]);
+    for (int64_t i = 0; i < n; ++i) {
         if (y[i] < 0 || y[i] >= t->K) return mmc_fail(MMC_ERR_ARG, "label index y[%lld] = %d outside [0, %d)", (long long)i, y[i], t->K);
+        if (order && (order[i] < 0 || order[i] >= n)) return mmc_fail(MMC_ERR_ARG, "order[%lld] = %lld outside [0, %lld)", (long long)i, (long long)order[i], (long long)n);
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     T_TRY(hipSetDevice(t->device));
     const int mb = (int)(batch_size < n ? batch_size : n);
     const int steps = (int)((n + mb - 1) / mb);
     int r = trainer_reserve(t, n, mb, steps);
     if (r) return r;
-    T_TRY(hipMemcpyAsync(t->X, X, (size_t)n * t->dims[0] * 4, hipMemcpyHostToDevice, st));
-    T_TRY(hipMemcpyAsync(t->y, y, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (order) {
+        if (n > t->cap_nn) {
+            hipFree(t->Xn); hipFree(t->yn); hipFree(t->order);
+            t->Xn = nullptr; t->yn = nullptr; t->order = nullptr; t->cap_nn = 0;
+            T_TRY(hipMalloc((void**)&t->Xn, (size_t)n * t->dims[0] * 4 + 256));
+            T_TRY(hipMalloc((void**)&t->yn, (size_t)n * 4 + 256));
+            T_TRY(hipMalloc((void**)&t->order, (size_t)n * 8 + 256));
+            t->cap_nn = n;
+        }
+        T_TRY(hipMemcpyAsync(t->Xn, X, (size_t)n * t->dims[0] * 4, hipMemcpyHostToDevice, st));
+        T_TRY(hipMemcpyAsync(t->yn, y, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        T_TRY(hipMemcpyAsync(t->order, order, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, t->Xn, t->yn, t->order, n, t->dims[0] / 4, t->X, t->y);
+    } else {
+        T_TRY(hipMemcpyAsync(t->X, X, (size_t)n * t->dims[0] * 4, hipMemcpyHostToDevice, st));
+        T_TRY(hipMemcpyAsync(t->y, y, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
     std::vector<int> sizes(steps);
     for (int s = 0; s < steps; ++s) {
         const int64_t start = (int64_t)s * mb;
         const int cur = (int)((n - start) < mb ? (n - start) : mb);
         sizes[s] = cur;
         double wsum = 0.0;   // sum of the mini-batch's class weights (mean reduction of the weighted CE)
-        if (t->cw) { for (int i = 0; i < cur; ++i) wsum += t->cw_host[y[start + i]]; } else wsum = cur;
+        if (t->cw) { for (int i = 0; i < cur; ++i) wsum += t->cw_host[y[order ? order[start + i] : start + i]]; } else wsum = cur;
         if (!(wsum > 0.0)) return mmc_fail(MMC_ERR_ARG, "mini-batch %d has zero total class weight", s);
         r = trainer_step(t, start, cur, (float)(1.0 / wsum), t->losses + s, st);
         if (r) return r;
@@ -412,6 +451,12 @@ extern "C" int mmc_trainer_partial_fit(mmc_trainer* t, const float* X, const int
     for (int s = 0; s < steps; ++s) tot += (double)h[s] * sizes[s];   // torch_classifier.py:293-298: loss.item() * mb_size
     if (avg_loss) *avg_loss = tot / (double)n;
     return MMC_OK;
+}
+
+extern "C" int mmc_trainer_partial_fit(mmc_trainer* t, const float* X, const int32_t* y, int64_t n, int batch_size, double* avg_loss,
+                                       void* hip_stream)
+{
+    return mmc_trainer_partial_fit_ordered(t, X, y, nullptr, n, batch_size, avg_loss, hip_stream);
 }
 
 extern "C" int mmc_trainer_get_params(mmc_trainer* t, float* const* W, float* const* b)

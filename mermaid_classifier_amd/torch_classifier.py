@@ -150,12 +150,20 @@ class TorchMLPClassifier:
         order = np.arange(n_samples)
         if self.shuffle:
             rng.shuffle(order)
-        Xo = np.ascontiguousarray(X_arr[order])
-        yo = np.ascontiguousarray(y_indices[order].astype(np.int32))
         avg = C.c_double(0.0)
         di = _device_index(self.device)
-        _lib.check(_lib.lib().mmc_trainer_partial_fit(self._h, Xo.ctypes.data, yo.ctypes.data, n_samples, int(batch_size),
-                                                      C.byref(avg), _current_stream_ptr(di)))
+        if X_arr.shape[1] % 4 == 0:
+            # the visiting order is applied on the device (a gather kernel): no host-side copy of the shuffled matrix
+            Xn = np.ascontiguousarray(X_arr)
+            yn = np.ascontiguousarray(y_indices.astype(np.int32))
+            od = np.ascontiguousarray(order.astype(np.int64))
+            _lib.check(_lib.lib().mmc_trainer_partial_fit_ordered(self._h, Xn.ctypes.data, yn.ctypes.data, od.ctypes.data, n_samples,
+                                                                  int(batch_size), C.byref(avg), _current_stream_ptr(di)))
+        else:
+            Xo = np.ascontiguousarray(X_arr[order])
+            yo = np.ascontiguousarray(y_indices[order].astype(np.int32))
+            _lib.check(_lib.lib().mmc_trainer_partial_fit(self._h, Xo.ctypes.data, yo.ctypes.data, n_samples, int(batch_size),
+                                                          C.byref(avg), _current_stream_ptr(di)))
         self.loss_curve_.append(float(avg.value))
         self.n_iter_ += 1
         return self
