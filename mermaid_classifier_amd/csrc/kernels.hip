@@ -3371,6 +3371,21 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
         const int iy0 = 2 * wy0;
         const int rows = 2 * wh + 1;
         const float pv0 = padval[0], pv1 = padval[1], pv2 = padval[2];
+        // Tiles that touch neither the right nor the bottom image edge need no padding values: four bytes -> four exact fp16
+        // (u8 - 128) with v_cvt_f32_ubyteN + packed converts and ONE 8-byte LDS store (the per-byte path below spends ~12
+        // instructions per byte on pixel/channel bookkeeping).  Same values either way.
+        const bool interior = tx < 6 && ty < 6;   // workgroup-uniform
+        if (interior) {
+            for (int i = tid; i < rows * 31; i += 256) {
+                const int r = i / 31, d = i - r * 31;
+                const int boff = icol0 * 3 + d * 4;
+                uint32_t word = 0;
+                if (boff >= 0) word = *reinterpret_cast<const uint32_t*>(img + (size_t)(iy0 + r) * 672 + boff);   // (boff < 0: columns never used)
+                h4 v = {(_Float16)((float)(word & 0xffu) - 128.0f), (_Float16)((float)((word >> 8) & 0xffu) - 128.0f),
+                        (_Float16)((float)((word >> 16) & 0xffu) - 128.0f), (_Float16)((float)(word >> 24) - 128.0f)};
+                *reinterpret_cast<h4*>(tile + r * SD_ROWH + d * 4) = v;   // (row stride 128 halves: the 124th half is spare)
+            }
+        } else
         for (int i = tid; i < rows * 31; i += 256) {
             const int r = i / 31, d = i - r * 31;
             const int iy = iy0 + r;
