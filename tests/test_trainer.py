@@ -136,3 +136,26 @@ def test_hip_trainer_production_shape_against_oracle():
         print(f"{a.shape}: mean {d.mean():.2e} p99.9 {np.quantile(d, 0.999):.2e} max {d.max():.2e}")
         assert np.quantile(d, 0.999) < W_TOL and d.max() < 2e-4
     assert np.abs(clf.predict_proba(X[:50]) - ref.predict_proba(X[:50])).max() < P_TOL
+
+
+@pytest.mark.gpu
+def test_hip_trainer_odd_feature_width_takes_the_host_shuffle_path():
+    """A feature width that is not a multiple of 4 cannot use the device-side gather (float4 rows): the host applies the
+    visiting order instead (mmc_trainer_partial_fit); both paths must follow the oracle."""
+    from mermaid_classifier_amd.torch_classifier import TorchMLPClassifier
+    from oracle.mlp_train_ref import MLPTrainRef
+    rng = np.random.default_rng(2)
+    k, nf, n = 5, 10, 333
+    yi = rng.integers(0, k, size=n)
+    X = (rng.normal(0, 1, size=(k, nf))[yi] + rng.normal(0, 1, size=(n, nf))).astype(np.float32)
+    clf = TorchMLPClassifier(hidden_layer_sizes=(16,), batch_size=50, random_state=1)
+    clf.classes_, clf.n_features_in_ = np.arange(k), nf
+    w0, b0 = clf._initial_parameters()
+    del clf.classes_, clf.n_features_in_
+    ref = MLPTrainRef(w0, b0)
+    want = [ref.partial_fit(X, yi, 50, random_state=1) for _ in range(2)]
+    for _ in range(2):
+        clf.partial_fit(X, yi, classes=list(range(k)))
+    np.testing.assert_allclose(clf.loss_curve_, want, atol=LOSS_TOL)
+    for a, b in zip(clf.parameters()[0], ref.W):
+        assert np.abs(a - b).max() < W_TOL
