@@ -8,7 +8,17 @@ One "step" = one pass of the hot path over one batch of 256 synthetic 224x224 u8
 GPU (BASELINE.json configs[1]: "EfficientNet-B0 forward, batch=256 random 224x224 patches"),
 resident in HBM before the timed region; for N > 1 ranks hold independent shards (weak scaling)
 and the step ends with the RCCL all-gather of the (N*256, 1280) feature matrix (configs[3]).
+Steps rotate over NBUF distinct input batches (308 MB > the 256 MB Infinity Cache), so the
+compulsory input bytes of a step come from HBM, as they would in a real run.
 Rank 0 prints ONE JSON line.  The oracle is imported only for the cpu_baseline leg.
+
+`--gpus N` with N > 1 from a plain `python bench.py` (no WORLD_SIZE in the environment) launches
+the N ranks itself: N child processes of this script with RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set, started BEFORE this process touches torch or the GPU; rank 0's
+JSON line is passed through and the exit status is non-zero when any rank fails (the reference's
+fan-out: scripts/launch_processing.py:59-66, 199-233).  `--dry-run` exercises exactly that
+plumbing -- launcher, rendezvous, barrier / MAX-over-ranks timing, ragged all-gather -- on the
+gloo backend with rank-tagged blocks instead of features: no GPU, no backbone, `value` null.
 """
 
 from __future__ import annotations
@@ -27,6 +37,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 BATCH = 256
+NBUF = 8      # distinct input batches the steps rotate over: 8 x 38.5 MB > 256 MB of Infinity Cache
 
 
 def synth_weights():
@@ -81,6 +92,79 @@ def cpu_baseline(sd, budget_s: float = 15.0):
             "sample": f"{n // 10} x (1 image 4872x5568 x 10 points: crop+transform+B0 fp32 batch 10+tolist), torch CPU {torch.get_num_threads()} threads"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which has not
+    imported torch or touched the GPU (and never does).  Rank 0 inherits stdout (the JSON line); the other ranks'
+    stdout goes to stderr.  Returns the exit status: 0 only if every rank exited 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    try:
+        for r, p in enumerate(procs):
+            rc = p.wait()
+            if rc != 0:
+                print(f"bench.py: rank {r} exited with status {rc}", file=sys.stderr)
+                status = status or (rc if rc > 0 else 1)
+                for q in procs:        # a dead rank leaves the others waiting in a collective
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return status
+
+
+def dry_run(args, json_out) -> None:
+    """The multi-rank plumbing without a GPU: gloo rendezvous, the step loop's barrier / MAX-over-ranks timing and the
+    ragged all-gather of dist.gather_features on rank-tagged blocks.  Measures nothing: `value` is null."""
+    import torch
+    import torch.distributed as dist
+    from mermaid_classifier_amd.dist import gather_features, shard_range
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("MMC_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole run
+        os._exit(3)
+    n_total = world * 5 + (world - 1)            # ragged on purpose
+    lo, hi = shard_range(n_total, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1).repeat(1, 8)
+    for _ in range(args.warmup):
+        gather_features(local, n_total)
+    dist.barrier()
+    t0 = time.perf_counter()
+    full = gather_features(local, n_total)
+    for _ in range(args.steps - 1):
+        full = gather_features(local, n_total)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = full.shape == (n_total, 8) and bool(torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"metric": "patches/sec (224x224 EfficientNet-B0)", "value": None, "unit": "patches/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "none (dry run)",
+                          "config": {"workload": "dry run: launcher + gloo rendezvous + ragged all-gather of rank-tagged blocks, no GPU work",
+                                     "parallelism": f"patch-sharded x{world}"}, "dry_run": True, "gather_ok": ok}),
+              file=json_out, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry run: gathered matrix is not in global patch order")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,7 +172,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=5)
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / gather plumbing on gloo, no GPU work")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))     # nothing above has imported torch or touched the GPU
 
     # The JSON line must be the only thing on stdout: RCCL prints a five-line version banner to fd 1 when a communicator is
     # created (N > 1).  Keep the real stdout aside for the JSON line and point fd 1 at stderr for everything else.
@@ -96,16 +185,17 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.dry_run:
+        return dry_run(args, json_out)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -120,7 +210,8 @@ def main():
     sd = synth_weights()
     bb = Backbone(sd, device=local_rank, max_batch=BATCH)
     rng = np.random.default_rng(42 + rank)
-    patches = torch.from_numpy(rng.integers(0, 255, (BATCH, 224, 224, 3), dtype=np.uint8)).to(dev)
+    pbufs = [torch.from_numpy(rng.integers(0, 255, (BATCH, 224, 224, 3), dtype=np.uint8)).to(dev) for _ in range(NBUF)]
+    patches = pbufs[0]
     feats = torch.empty((BATCH, 1280), dtype=torch.float32, device=dev)
 
     from mermaid_classifier_amd.dist import gather_features
@@ -141,8 +232,10 @@ def main():
     counter = [0]
 
     def step():
+        src = pbufs[counter[0] % NBUF]     # a fresh batch every step: input bytes come from HBM, not from the Infinity Cache
         if not overlap:
-            bb.extract(patches, out=feats)
+            counter[0] += 1
+            bb.extract(src, out=feats)
             if use_dist:
                 gather_features(feats, world * BATCH)   # one RCCL all-gather of the (BATCH,1280) blocks
             return
@@ -150,7 +243,7 @@ def main():
         counter[0] += 1
         if pending[i] is not None:
             pending[i].wait()          # the collective that read fbuf[i] / wrote gbuf[i] two steps ago (stream-level wait)
-        bb.extract(patches, out=fbuf[i])
+        bb.extract(src, out=fbuf[i])
         pending[i] = dist.all_gather_into_tensor(gbuf[i], fbuf[i], async_op=True)
 
     def drain():
@@ -162,7 +255,7 @@ def main():
     # Engine initialisation, before the W warm-up steps: the library captures a pass into a HIP graph the third time the same
     # buffers come in (mmc_api.cpp run_pass) -- a one-off cost of a few ms that belongs to set-up like the weights upload, so
     # that a small W cannot push it into the timed region.
-    for _ in range(3):
+    for _ in range(3 * NBUF * (2 if overlap else 1)):   # every (input, output) combination seen three times: its graph exists
         step()
     for _ in range(args.warmup):
         step()
@@ -243,6 +336,7 @@ def main():
             "config": {"workload": "EfficientNet-B0 forward, batch=256 random 224x224 u8 patches per GPU -> (256,1280) fp32"
                                    + ("; RCCL all-gather of features" + (" overlapped with the next step" if overlap else "") if world > 1 else ""),
                        "per_gpu_batch": BATCH, "global_batch": world * BATCH, "weights": "synthetic seed 0",
+                       "input_batches_rotated": NBUF,
                        "lanes_per_gpu": bb.lanes,
                        "parallelism": f"patch-sharded x{world}"},
             "roofline": roofline,

@@ -75,10 +75,15 @@ size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb);
 
 /* patches: n x 224 x 224 x 3 u8 (HWC, RGB).  out_features: n x feature_dim fp32, row i = patch i.
  * flags: MMC_IN_HOST | MMC_OUT_HOST select host pointers; default both device pointers.
- * Asynchronous on `hip_stream` unless MMC_OUT_HOST is set.  A handle is used from one thread at a time (the
- * reference's forward path is single-threaded: scripts/build_feature_bucket.py, "one extractor instance per process").
+ * Asynchronous on `hip_stream` unless MMC_OUT_HOST is set.  One pass at a time per handle (the reference's forward path
+ * is single-threaded: scripts/build_feature_bucket.py, "one extractor instance per process"): concurrent calls on one
+ * handle are serialised by a per-handle mutex, and a call that comes in on a different stream than the previous one first
+ * waits (on the device) for that call's work, because the workspace is shared.  For concurrency create one handle per
+ * stream.
  * When the same (patches, out_features, n) combination comes in repeatedly the pass is captured into a HIP graph
- * once and replayed on `hip_stream` afterwards (env MMC_GRAPH=0 disables); results are identical either way. */
+ * once and replayed on `hip_stream` afterwards (env MMC_GRAPH=0 disables); results are identical either way.  The 32
+ * most recently used combinations keep their graph; callers that cycle through more buffers than that fall back to plain
+ * launches for the evicted ones until they repeat. */
 int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
                          unsigned flags, void* hip_stream);
 
@@ -104,6 +109,8 @@ int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, int64_t n, f
  *    mermaid_classifier/pyspacer/annotation.py:241): reflect-pad by 224, slice 224x224 around
  *   each (row,col).  Implemented as index arithmetic on the resident image (no padded copy).
  * image: H x W x 3 u8; rowcols: n x 2 int32 (row, col); patches_out: n x 224 x 224 x 3 u8 (device).
+ * Points must lie inside the image: host points (MMC_IN_HOST) outside it are rejected with MMC_ERR_ARG; device-resident
+ * points cannot be inspected by the host and are clamped into the image by the kernel (never an out-of-bounds read).
  * With MMC_IN_HOST and few points on a big image (n * 150528 * 6 <= image bytes -- the reference's data: 10-25 points on a
  * 27 MP image) the patches are cut on the host (same index arithmetic, up to 4 threads, into a pinned ring slot) and only
  * they are uploaded; otherwise the image is uploaded and crop_kernel cuts them.  Same bytes either way.  The host image is
@@ -133,10 +140,12 @@ int mmc_head_predict(mmc_head* h, const float* feats, int64_t n, float* proba, i
  * The host side keeps what the reference keeps on the host: classes_/label lookup, Glorot initialisation (torch RNG, so
  * the same random_state gives the same initial weights), the shuffle order, loss_curve_/n_iter_ bookkeeping.
  * W[l]: (dims[l+1], dims[l]) row-major fp32, b[l]: (dims[l+1]) -- the initial parameters (host pointers);
- * class_weight: K floats in classes_ order or NULL; Adam moments start at zero, step count at 0. */
+ * class_weight: K floats in classes_ order or NULL; Adam moments start at zero, step count at 0.
+ * Hyper-parameters are doubles because torch derives its fp32 scalars (1 - beta, lr / bias_correction, alpha / mb) from
+ * python floats: (float)(1.0 - 0.9) is not 1.0f - 0.9f. */
 typedef struct mmc_trainer mmc_trainer;
-int mmc_trainer_create(const float* const* W, const float* const* b, const int* dims, int n_layers, float lr, float beta1,
-                       float beta2, float eps, float alpha, const float* class_weight, int device, mmc_trainer** out);
+int mmc_trainer_create(const float* const* W, const float* const* b, const int* dims, int n_layers, double lr, double beta1,
+                       double beta2, double eps, double alpha, const float* class_weight, int device, mmc_trainer** out);
 void mmc_trainer_destroy(mmc_trainer* t);
 /* One pass over n samples ALREADY IN VISITING ORDER (the caller applies the shuffle, torch_classifier.py:251-257):
  * X n x dims[0] fp32 and y n int32 class indices, host pointers; mini-batches of `batch_size` rows (last one ragged),

@@ -83,8 +83,9 @@ def _load() -> C.CDLL:
     lib.mmc_head_predict.restype = i32
     lib.mmc_head_predict.argtypes = [vp, vp, i64, vp, vp, u32, vp]
     f32 = C.c_float
+    f64 = C.c_double
     lib.mmc_trainer_create.restype = i32
-    lib.mmc_trainer_create.argtypes = [C.POINTER(fp), C.POINTER(fp), C.POINTER(i32), i32, f32, f32, f32, f32, f32, fp, i32, C.POINTER(vp)]
+    lib.mmc_trainer_create.argtypes = [C.POINTER(fp), C.POINTER(fp), C.POINTER(i32), i32, f64, f64, f64, f64, f64, fp, i32, C.POINTER(vp)]
     lib.mmc_trainer_destroy.restype = None
     lib.mmc_trainer_destroy.argtypes = [vp]
     lib.mmc_trainer_partial_fit.restype = i32

@@ -1015,7 +1015,11 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ i
     const int idx = blockIdx.x * 256 + threadIdx.x;  // over 224*56 groups of 4 pixels
     if (idx >= 224 * 56) return;
     const int y = idx / 56, xg = idx - y * 56;
-    const int row = rowcols[2 * p], col = rowcols[2 * p + 1];
+    // device-resident points have not been seen by the host: clamp them into the image so that a bad point can never
+    // turn into an out-of-bounds read (the host-points path rejects such points with MMC_ERR_ARG before launching)
+    int row = rowcols[2 * p], col = rowcols[2 * p + 1];
+    row = row < 0 ? 0 : (row >= H ? H - 1 : row);
+    col = col < 0 ? 0 : (col >= W ? W - 1 : col);
     int sy = row - 112 + y;
     sy = sy < 0 ? -sy : sy;
     sy = sy >= H ? 2 * (H - 1) - sy : sy;

@@ -206,6 +206,8 @@ struct Saved {
     bool is_half = true;
 };
 
+#define MMC_GRAPH_CACHE 32   // captured (input, output, n) combinations kept per handle
+
 struct mmc_backbone {
     int device = 0, max_batch = 0;
     int arch = MMC_ARCH_B0, nblk = 16, stem_ch = 32, head_in = 320, feat = 1280;
@@ -225,6 +227,7 @@ struct mmc_backbone {
     Lane lanes[4];
     // optional (MMC_GRAPH=1): a pass over device-resident buffers is captured once per (input, output, n) into a HIP graph
     // and replayed -- the ~26 launches per lane then cost one graph launch
+    // (least recently used entry evicted beyond MMC_GRAPH_CACHE combinations)
     struct GraphEntry { const void* in; float* out; int n; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     bool use_graph = false;
@@ -260,6 +263,29 @@ struct mmc_backbone {
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     std::map<std::string, Saved> saved;
     int last_n = 0;
+    // One pass at a time per handle (lane workspaces, fork/done events and the staging buffers are shared): calls are
+    // serialised on the host by `mu`, and a call on a different stream than the previous one waits for that one's work.
+    std::mutex mu;
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+};
+
+// serialise against the previous call's device work when the caller switches streams; record this call's end
+struct PassOrder {
+    mmc_backbone* bb; hipStream_t st; bool armed = false;
+    int begin()
+    {
+        if (bb->have_last && bb->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, bb->last_done, 0));
+        armed = true;
+        return 0;
+    }
+    ~PassOrder()
+    {
+        if (!armed) return;
+        if (!bb->last_done && hipEventCreateWithFlags(&bb->last_done, hipEventDisableTiming) != hipSuccess) { bb->last_done = nullptr; return; }
+        if (hipEventRecord(bb->last_done, st) == hipSuccess) { bb->last_stream = st; bb->have_last = true; }
+    }
 };
 
 struct ProfEntry { std::string name; hipEvent_t e0, e1; };
@@ -357,6 +383,7 @@ extern "C" void mmc_backbone_destroy(mmc_backbone* bb)
         if (bb->lanes[l].done) hipEventDestroy(bb->lanes[l].done);
     }
     if (bb->fork) hipEventDestroy(bb->fork);
+    if (bb->last_done) hipEventDestroy(bb->last_done);
     for (auto& g : bb->graphs) hipGraphExecDestroy(g.exec);
     if (bb->gstream) hipStreamDestroy(bb->gstream);
     delete bb;
@@ -1146,18 +1173,24 @@ static int forward_pass(mmc_backbone* bb, const uint8_t* patches_dev, int n, flo
 static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hipStream_t st)
 {
     if (!bb->use_graph || n > 8 * bb->max_batch) return forward_pass(bb, pin, n, pout, st, nullptr);   // (bounded graph size)
-    for (auto& g : bb->graphs)
+    for (size_t gi = 0; gi < bb->graphs.size(); ++gi) {
+        const mmc_backbone::GraphEntry g = bb->graphs[gi];
         if (g.in == pin && g.out == pout && g.n == n) {
+            if (gi + 1 != bb->graphs.size()) {   // most recently used last
+                bb->graphs.erase(bb->graphs.begin() + (long)gi);
+                bb->graphs.push_back(g);
+            }
             HIP_TRY(hipGraphLaunch(g.exec, st));
             return 0;
         }
+    }
     bool repeat = false;
     for (auto& k : bb->seen) repeat = repeat || (k.in == pin && k.out == pout && k.n == n);
     if (!repeat) {
-        if (bb->seen.size() >= 16) bb->seen.erase(bb->seen.begin());
+        if (bb->seen.size() >= 2 * MMC_GRAPH_CACHE) bb->seen.erase(bb->seen.begin());
         bb->seen.push_back({pin, pout, n});
     }
-    if (bb->graph_warm < 2 || !repeat || bb->graphs.size() >= 8) {   // first passes un-captured: lazy per-kernel attribute setup happens there
+    if (bb->graph_warm < 2 || !repeat) {   // first passes un-captured: lazy per-kernel attribute setup happens there
         ++bb->graph_warm;
         return forward_pass(bb, pin, n, pout, st, nullptr);
     }
@@ -1177,6 +1210,12 @@ static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hi
         bb->use_graph = false;
         return forward_pass(bb, pin, n, pout, st, nullptr);
     }
+    if (bb->graphs.size() >= MMC_GRAPH_CACHE) {
+        // least recently used graph goes; it may still be executing on a stream this handle was given earlier
+        HIP_TRY(hipDeviceSynchronize());
+        hipGraphExecDestroy(bb->graphs.front().exec);
+        bb->graphs.erase(bb->graphs.begin());
+    }
     bb->graphs.push_back({pin, pout, n, exec});
     HIP_TRY(hipGraphLaunch(exec, st));
     return 0;
@@ -1190,7 +1229,10 @@ extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64
     if (n == 0) return MMC_OK;
     if (!patches || !out_features) return fail(MMC_ERR_ARG, "patches/out_features is NULL");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> lock(bb->mu);
     HIP_TRY(hipSetDevice(bb->device));
+    PassOrder order{bb, st};
+    { int r = order.begin(); if (r) return r; }
     const size_t psz = (size_t)IMG * IMG * 3;
     const uint8_t* in = static_cast<const uint8_t*>(patches);
     if (!(flags & (MMC_IN_HOST | MMC_OUT_HOST)) && !bb->keep) {
@@ -1254,7 +1296,10 @@ extern "C" int mmc_backbone_profile(mmc_backbone* bb, const void* patches_dev, i
         return fail(MMC_ERR_ARG, "NULL argument");
     if (n < 1 || n > bb->max_batch) return fail(MMC_ERR_ARG, "n must be in [1, max_batch]");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    std::lock_guard<std::mutex> lock(bb->mu);
     HIP_TRY(hipSetDevice(bb->device));
+    PassOrder order{bb, st};
+    { int r = order.begin(); if (r) return r; }
     Prof prof;
     int r = forward_pass(bb, static_cast<const uint8_t*>(patches_dev), (int)n, out_features_dev, st, &prof);
     if (r) return r;
@@ -1286,6 +1331,9 @@ struct PinnedSlot { void* host = nullptr; size_t cap = 0; hipEvent_t ev = nullpt
 PinnedSlot g_slots[4];
 int g_slot_next = 0;
 std::mutex g_slot_mu;
+// upload path of mmc_crop_patches (dense points on a host image): per-device staging buffers kept between calls
+struct CropStage { void* img = nullptr; size_t img_cap = 0; void* rc = nullptr; size_t rc_cap = 0; hipEvent_t ev = nullptr; };
+CropStage g_crop_stage[16];
 }  // namespace
 
 static int crop_on_host(const uint8_t* img, int H, int W, const int32_t* rowcols, int64_t n, void* out_dev, hipStream_t st)
@@ -1351,8 +1399,6 @@ extern "C" int mmc_crop_patches(const void* image, int height, int width, const 
     HIP_TRY(hipSetDevice(device));
     const uint8_t* img = static_cast<const uint8_t*>(image);
     const int32_t* rc = rowcols;
-    void* tmp_img = nullptr;
-    void* tmp_rc = nullptr;
     if (flags & MMC_IN_HOST) {
         for (int64_t i = 0; i < n; ++i) {
             const int r = rowcols[2 * i], c = rowcols[2 * i + 1];
@@ -1366,19 +1412,37 @@ extern "C" int mmc_crop_patches(const void* image, int height, int width, const 
         static const int force = [] { const char* e = getenv("MMC_CROP_HOST"); return e ? atoi(e) : -1; }();
         const bool host_crop = force >= 0 ? force != 0 : (size_t)n * IMG * IMG * 3 * 6 <= ib;
         if (host_crop) return crop_on_host(img, height, width, rowcols, n, patches_out_dev, st);
-        HIP_TRY(hipMalloc(&tmp_img, ib));
-        HIP_TRY(hipMalloc(&tmp_rc, (size_t)n * 8));
-        HIP_TRY(hipMemcpyAsync(tmp_img, image, ib, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(tmp_rc, rowcols, (size_t)n * 8, hipMemcpyHostToDevice, st));
-        img = static_cast<const uint8_t*>(tmp_img);
-        rc = static_cast<const int32_t*>(tmp_rc);
+        // dense points: upload the image once into a per-device staging buffer that is kept between calls (grown on demand)
+        std::lock_guard<std::mutex> lock(g_slot_mu);
+        CropStage& cs = g_crop_stage[device & 15];
+        const size_t rb = (size_t)n * 8;
+        if (cs.img_cap < ib) {
+            if (cs.img) { hipStreamSynchronize(st); hipFree(cs.img); }
+            cs.img = nullptr; cs.img_cap = 0;
+            HIP_TRY(hipMalloc(&cs.img, ib));
+            cs.img_cap = ib;
+        }
+        if (cs.rc_cap < rb) {
+            if (cs.rc) { hipStreamSynchronize(st); hipFree(cs.rc); }
+            cs.rc = nullptr; cs.rc_cap = 0;
+            HIP_TRY(hipMalloc(&cs.rc, rb));
+            cs.rc_cap = rb;
+        }
+        // the previous call's kernel may still be reading the staging buffers on another stream
+        if (cs.ev) HIP_TRY(hipStreamWaitEvent(st, cs.ev, 0));
+        else HIP_TRY(hipEventCreateWithFlags(&cs.ev, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(cs.img, image, ib, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(cs.rc, rowcols, rb, hipMemcpyHostToDevice, st));
+        int r = launch_crop(static_cast<const uint8_t*>(cs.img), height, width, static_cast<const int32_t*>(cs.rc), (int)n,
+                            static_cast<uint8_t*>(patches_out_dev), st);
+        HIP_TRY(hipEventRecord(cs.ev, st));
+        // the host image / rowcols are pageable caller memory the caller may free or overwrite right after this call
+        HIP_TRY(hipStreamSynchronize(st));
+        if (r) return fail(MMC_ERR_HIP, "crop kernel launch failed (%d)", r);
+        return MMC_OK;
     }
+    // device-resident image and points: the kernel clamps each point into the image (see crop_kernel)
     int r = launch_crop(img, height, width, rc, (int)n, static_cast<uint8_t*>(patches_out_dev), st);
-    if (tmp_img) {
-        hipStreamSynchronize(st);
-        hipFree(tmp_img);
-        hipFree(tmp_rc);
-    }
     if (r) return fail(MMC_ERR_HIP, "crop kernel launch failed (%d)", r);
     return MMC_OK;
 }

@@ -182,14 +182,15 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 //   exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
 //   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps;  param.addcdiv_(exp_avg, denom, value=-(lr / (1 - beta1^t)))
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float step_size,
-                                                   float bc2_sqrt)
+                                                   float* __restrict__ v, size_t n, float om_beta1, float beta2, float om_beta2, float eps,
+                                                   float step_size, float bc2_sqrt)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
-    const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);
-    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    // om_beta = (float)(1.0 - (double)beta): torch forms 1 - beta in double and casts the scalar, which is not 1.0f - (float)beta
+    const float mi = m[i] + om_beta1 * (gi - m[i]);
+    const float vi = v[i] * beta2 + om_beta2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
@@ -246,7 +247,7 @@ struct mmc_trainer {
     int64_t* order = nullptr;
     int64_t cap_n = 0, cap_nn = 0;
     int cap_mb = 0, cap_steps = 0;
-    float lr = 1e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, alpha = 1e-4f;
+    double lr = 1e-3, beta1 = 0.9, beta2 = 0.999, eps = 1e-8, alpha = 1e-4;   // kept in double: torch derives its fp32 scalars from python floats
     long long t = 0;                                    // Adam step count
     std::vector<float> cw_host;
 };
@@ -280,8 +281,8 @@ extern "C" void mmc_trainer_destroy(mmc_trainer* t)
     delete t;
 }
 
-extern "C" int mmc_trainer_create(const float* const* W, const float* const* b, const int* dims, int n_layers, float lr, float beta1,
-                                  float beta2, float eps, float alpha, const float* class_weight, int device, mmc_trainer** out)
+extern "C" int mmc_trainer_create(const float* const* W, const float* const* b, const int* dims, int n_layers, double lr, double beta1,
+                                  double beta2, double eps, double alpha, const float* class_weight, int device, mmc_trainer** out)
 {
     if (!out) return mmc_fail(MMC_ERR_ARG, "out is NULL");
     *out = nullptr;
@@ -289,7 +290,7 @@ extern "C" int mmc_trainer_create(const float* const* W, const float* const* b, 
     if (n_layers < 1 || n_layers > 16) return mmc_fail(MMC_ERR_ARG, "n_layers %d out of range [1,16]", n_layers);
     for (int l = 0; l <= n_layers; ++l)
         if (dims[l] < 1) return mmc_fail(MMC_ERR_ARG, "dims[%d]=%d must be positive", l, dims[l]);
-    if (!(lr > 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps >= 0.f) || !(alpha >= 0.f))
+    if (!(lr > 0.) || !(beta1 >= 0. && beta1 < 1.) || !(beta2 >= 0. && beta2 < 1.) || !(eps >= 0.) || !(alpha >= 0.))
         return mmc_fail(MMC_ERR_ARG, "bad optimizer hyper-parameter (lr %g, betas %g %g, eps %g, alpha %g)", lr, beta1, beta2, eps, alpha);
     const int K = dims[n_layers];
     if (class_weight)
@@ -372,23 +373,24 @@ static int trainer_step(mmc_trainer* t, int64_t start, int mb, float inv_wsum, f
     // regularised loss of this mini-batch (before the update): data + (0.5 alpha / mb) sum W^2
     for (int l = 0; l < L; ++l)
         hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, st, t->W[l], (size_t)t->dims[l + 1] * t->dims[l], t->partials + 256 * l);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, t->row_loss, mb, t->partials, 256 * L, 0.5f * t->alpha / (float)mb,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, t->row_loss, mb, t->partials, 256 * L, (float)(0.5 * t->alpha / (double)mb),
                        loss_slot);
     for (int l = L - 1; l >= 0; --l) {
         const int no = t->dims[l + 1], ni = t->dims[l];
-        T_K((launch_tgemm<true, false>(t->dZ[l + 1], t->H[l], t->gW[l], no, ni, mb, TEPI_L2, t->W[l], t->alpha / (float)mb, st)));
+        T_K((launch_tgemm<true, false>(t->dZ[l + 1], t->H[l], t->gW[l], no, ni, mb, TEPI_L2, t->W[l], (float)(t->alpha / (double)mb), st)));
         hipLaunchKernelGGL(colsum_kernel, dim3((no + 255) / 256), dim3(256), 0, st, t->dZ[l + 1], mb, no, t->gb[l]);
         if (l > 0) T_K((launch_tgemm<false, false>(t->dZ[l + 1], t->W[l], t->dZ[l], mb, ni, no, TEPI_MASK, t->H[l], 0.f, st)));
     }
     ++t->t;
-    const double bc1 = 1.0 - std::pow((double)t->beta1, (double)t->t), bc2 = 1.0 - std::pow((double)t->beta2, (double)t->t);
-    const float step_size = (float)((double)t->lr / bc1), bc2_sqrt = (float)std::sqrt(bc2);
+    const double bc1 = 1.0 - std::pow(t->beta1, (double)t->t), bc2 = 1.0 - std::pow(t->beta2, (double)t->t);
+    const float step_size = (float)(t->lr / bc1), bc2_sqrt = (float)std::sqrt(bc2);
+    const float om1 = (float)(1.0 - t->beta1), om2 = (float)(1.0 - t->beta2), b2f = (float)t->beta2, epsf = (float)t->eps;
     for (int l = 0; l < L; ++l) {
         const size_t nw = (size_t)t->dims[l + 1] * t->dims[l], nb = (size_t)t->dims[l + 1];
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, t->W[l], t->gW[l], t->mW[l], t->vW[l], nw,
-                           t->beta1, t->beta2, t->eps, step_size, bc2_sqrt);
+                           om1, b2f, om2, epsf, step_size, bc2_sqrt);
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, t->b[l], t->gb[l], t->mb[l], t->vb[l], nb,
-                           t->beta1, t->beta2, t->eps, step_size, bc2_sqrt);
+                           om1, b2f, om2, epsf, step_size, bc2_sqrt);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return mmc_fail(MMC_ERR_HIP, "trainer step launch failed: %s", hipGetErrorString(e));
@@ -414,6 +416,17 @@ extern "C" int mmc_trainer_partial_fit_ordered(mmc_trainer* t, const float* X, c
     T_TRY(hipSetDevice(t->device));
     const int mb = (int)(batch_size < n ? batch_size : n);
     const int steps = (int)((n + mb - 1) / mb);
+    // every mini-batch's weight sum (mean reduction of the weighted CE) is checked BEFORE anything is uploaded or launched, so
+    // a rejected pass leaves the weights, the Adam moments and the step counter exactly as they were
+    std::vector<double> wsums(steps);
+    for (int s = 0; s < steps; ++s) {
+        const int64_t start = (int64_t)s * mb;
+        const int cur = (int)((n - start) < mb ? (n - start) : mb);
+        double wsum = 0.0;
+        if (t->cw) { for (int i = 0; i < cur; ++i) wsum += t->cw_host[y[order ? order[start + i] : start + i]]; } else wsum = cur;
+        if (!(wsum > 0.0)) return mmc_fail(MMC_ERR_ARG, "mini-batch %d has zero total class weight", s);
+        wsums[s] = wsum;
+    }
     int r = trainer_reserve(t, n, mb, steps);
     if (r) return r;
     if (order) {
@@ -438,10 +451,7 @@ extern "C" int mmc_trainer_partial_fit_ordered(mmc_trainer* t, const float* X, c
         const int64_t start = (int64_t)s * mb;
         const int cur = (int)((n - start) < mb ? (n - start) : mb);
         sizes[s] = cur;
-        double wsum = 0.0;   // sum of the mini-batch's class weights (mean reduction of the weighted CE)
-        if (t->cw) { for (int i = 0; i < cur; ++i) wsum += t->cw_host[y[order ? order[start + i] : start + i]]; } else wsum = cur;
-        if (!(wsum > 0.0)) return mmc_fail(MMC_ERR_ARG, "mini-batch %d has zero total class weight", s);
-        r = trainer_step(t, start, cur, (float)(1.0 / wsum), t->losses + s, st);
+        r = trainer_step(t, start, cur, (float)(1.0 / wsums[s]), t->losses + s, st);
         if (r) return r;
     }
     std::vector<float> h(steps);

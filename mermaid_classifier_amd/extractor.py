@@ -15,11 +15,19 @@ is accepted too: ``device`` and ``batch_size`` are optional.
 When pyspacer is importable the class subclasses ``spacer.extractors.EfficientNetExtractor``
 (so pyspacer's message layer, storage and ``ImageFeatures`` are the real ones); otherwise it
 sits on ``spacer_shim.FeatureExtractorBase``.
+
+``device="cpu"`` is NOT a backend of this package: it exists only because the reference's numeric
+gate (``verify_device_numerics``, scripts/build_feature_bucket.py:475-480) builds its CPU side with
+``cls(..., device="cpu")`` from the very class factory the integration replaces.  With pyspacer
+installed such an instance runs pyspacer's own torch-CPU network exactly as the reference's
+``_DeviceCachingExtractor`` does (parent ``load_weights`` -> ``eval`` -> ``transformation()`` ->
+``net.extract_features``) -- the reference's arithmetic, none of ours; without pyspacer it raises.
 """
 
 from __future__ import annotations
 
-from typing import Any, List, Optional, Tuple
+import logging
+from typing import Any, Callable, List, Optional, Tuple
 
 import numpy as np
 
@@ -27,6 +35,7 @@ from . import spacer_shim
 from .backbone import Backbone, FEATURE_DIM, PATCH, crop_patches_device
 
 _DEFAULT_MAX_BATCH = 256
+logger = logging.getLogger(__name__)
 
 
 def resolve_device(name: str) -> str:
@@ -43,6 +52,10 @@ def resolve_device(name: str) -> str:
         if not torch.cuda.is_available():
             raise RuntimeError(f"--device {name} requested but torch.cuda.is_available() is False.")
         return name
+    if name == "cpu":
+        raise RuntimeError("--device cpu is not served by mermaid_classifier_amd: the CPU path is stock pyspacer "
+                           "(this package has no CPU backend; only the numerics gate builds a cpu-side extractor, "
+                           "and that needs pyspacer installed).")
     raise RuntimeError(f"--device {name} is not served by mermaid_classifier_amd (HIP only; use 'cuda').")
 
 
@@ -77,18 +90,33 @@ def _make_class(base, have_spacer: bool):
             self._batch_size = int(batch_size) if batch_size is not None else None
             if self._batch_size is not None and self._batch_size < 1:
                 raise ValueError(f"batch_size must be >= 1; got {batch_size}")
-            self._cached_net: Optional[Backbone] = None
+            self._cached_net: Optional[Any] = None       # Backbone, or pyspacer's torch net for device="cpu"
             self._cached_loaded_remote = False
+            if str(device) == "cpu" and not have_spacer:
+                raise RuntimeError("device='cpu' needs pyspacer: the CPU side of the numerics gate is pyspacer's own "
+                                   "torch network, and mermaid_classifier_amd has no CPU backend.")
 
         @property
         def feature_dim(self) -> int:
             return FEATURE_DIM
 
-        def _ensure_net(self) -> Tuple[Backbone, bool]:
+        @property
+        def _stock_cpu(self) -> bool:
+            return have_spacer and str(self._device) == "cpu"
+
+        def _ensure_net(self) -> Tuple[Any, bool]:
             # scripts/build_feature_bucket.py:402-413: build once, report loaded_remote once
             if self._cached_net is not None:
                 return self._cached_net, False
             weights_ds, loaded_remote = self.load_datastream("weights")
+            if self._stock_cpu:
+                # the reference's own CPU path (:406-410): pyspacer builds its torch model and loads the state dict
+                net = base.load_weights(weights_ds)
+                net = net.to("cpu")
+                net.eval()
+                self._cached_net = net
+                self._cached_loaded_remote = loaded_remote
+                return net, loaded_remote
             max_batch = max(self._batch_size or 0, _DEFAULT_MAX_BATCH) if self._batch_size is None else self._batch_size
             net = Backbone(weights_ds, device=resolve_device(self._device), max_batch=max_batch)
             self._cached_net = net
@@ -98,9 +126,27 @@ def _make_class(base, have_spacer: bool):
         def patches_to_features(self, patch_list: Any) -> Any:
             # scripts/build_feature_bucket.py:415-446
             net, loaded_remote = self._ensure_net()
+            if self._stock_cpu:
+                return self._stock_cpu_features(net, patch_list), loaded_remote
             arr = _patches_to_array(patch_list)
             feats = net.extract(arr)            # (N,1280) float32 on the host
             return feats.tolist(), loaded_remote
+
+        def _stock_cpu_features(self, net, patch_list) -> List[List[float]]:
+            """device="cpu" with pyspacer installed: pyspacer's transformation() and torch network on the CPU, batched as
+            the reference batches (:420-437).  Only the numerics gate comes here."""
+            import torch
+            from spacer.extractors.torch_extractors import transformation  # type: ignore
+
+            transformer = transformation()
+            bs = self._batch_size or self.BATCH_SIZE
+            feats: List[List[float]] = []
+            for b in range(0, len(patch_list), bs):
+                batch_t = torch.stack([transformer(i) for i in patch_list[b:b + bs]])
+                with torch.no_grad():
+                    out = net.extract_features(batch_t)
+                feats.extend(out.detach().to("cpu").tolist())
+            return feats
 
         # crop on the GPU when used through the shim base; with real pyspacer the parent's
         # __call__ does its own CPU crop_patches and hands PIL patches to patches_to_features.
@@ -143,18 +189,38 @@ def EfficientNetExtractor(*, data_locations, device: str = "cuda", batch_size: O
     return build_extractor_class()(data_locations=data_locations, device=device, batch_size=batch_size, **kwargs)
 
 
-def verify_device_numerics(extractor, cpu_features_fn, n_patches: int = 8, threshold: float = 0.999):
-    """The reference's only numeric gate for this path (scripts/build_feature_bucket.py:451-502):
-    min cosine similarity of device features vs CPU features on ``n_patches`` seed-42 random
-    patches must reach ``threshold``.  ``cpu_features_fn(list_of_uint8_patches) -> (N,1280)``
-    supplies the CPU side (stock pyspacer on cpu in production; the oracle in tests)."""
+def verify_device_numerics(extractor: Any, weights_loc: Any, batch_size: int, device: str, n_patches: int = 8,
+                           threshold: float = 0.999, *, cpu_features_fn: Optional[Callable] = None) -> None:
+    """The reference's only numeric gate for this path, with the reference's signature, logging and return value
+    (scripts/build_feature_bucket.py:451-502): device features vs CPU features on ``n_patches`` seed-42 random patches,
+    RuntimeError if the minimum cosine similarity is below ``threshold``; a no-op for ``device == "cpu"``.
+
+    The CPU side is built the way the reference builds it -- ``build_extractor_class()(data_locations={"weights":
+    weights_loc}, device="cpu", batch_size=batch_size)`` -- which is pyspacer's own torch-CPU network and therefore needs
+    pyspacer.  ``cpu_features_fn(list_of_patches) -> (N, dim)`` (keyword-only, not in the reference) substitutes another
+    CPU side, e.g. the oracle in the tests."""
+    if device == "cpu":
+        return
     rng = np.random.default_rng(seed=42)
-    patches = [rng.integers(0, 255, (PATCH, PATCH, 3), dtype=np.uint8) for _ in range(n_patches)]
+    arrays = [rng.integers(0, 255, (PATCH, PATCH, 3), dtype=np.uint8) for _ in range(n_patches)]
+    try:
+        from PIL import Image
+        patches: List[Any] = [Image.fromarray(a) for a in arrays]     # what pyspacer's transformation() takes
+    except ImportError:
+        patches = arrays
+    if cpu_features_fn is None:
+        cls = build_extractor_class()
+        cpu_extractor = cls(data_locations={"weights": weights_loc}, device="cpu", batch_size=batch_size)
+        cpu_feats, _ = cpu_extractor.patches_to_features(patches)
+    else:
+        cpu_feats = cpu_features_fn(arrays)
     device_feats, _ = extractor.patches_to_features(patches)
     a = np.asarray(device_feats)
-    b = np.asarray(cpu_features_fn(patches))
+    b = np.asarray(cpu_feats)
     sims = (a * b).sum(axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1) + 1e-12)
+    logger.info("Device numerics check (%s vs cpu, %d random patches): min_cos=%.6f median=%.6f max_abs_diff=%.4g",
+                device, n_patches, float(sims.min()), float(np.median(sims)), float(np.abs(a - b).max()))
     if sims.min() < threshold:
         raise RuntimeError(
-            f"Device numerics check FAILED: min cosine similarity {sims.min():.6f} < {threshold}.")
-    return float(sims.min()), float(np.median(sims)), float(np.abs(a - b).max())
+            f"Device numerics check FAILED on {device}: min cosine similarity {sims.min():.6f} < {threshold}. "
+            f"The features would not be safe to mix with previously CPU-extracted ones.")

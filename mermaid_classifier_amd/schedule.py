@@ -44,7 +44,9 @@ def b0_launches(batch: int) -> List[Launch]:
         out.append(Launch(f"b{i}.project", "project", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2,
                           2 * m_out * ce * cout))
         if i == 1:   # block 1's fused kernel with block 0's SE scale + project conv folded in (reads b0's depthwise output)
-            out.append(Launch("b0.project+b1.mbconv", "mbconv", m_in * 32 * 2 * 2 + m_out * ce * 2 + ce * cin * 2 + k * k * ce * 4,
+            # (block 0's depthwise output is counted ONCE, like every input: what the kernel re-reads per channel chunk
+            # shows up as PMC traffic above this figure)
+            out.append(Launch("b0.project+b1.mbconv", "mbconv", m_in * 32 * 2 + m_out * ce * 2 + ce * cin * 2 + k * k * ce * 4,
                               2 * m_in * cin * ce + 2 * m_out * ce * k * k + 2 * 2 * m_in * 32 * 16))
         if 3 <= i <= 10:   # squeeze-excite + project in one launch (proj_patch_kernel): no gate tensor in HBM
             out.append(Launch(f"b{i}.projse", "projse", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2 + 2 * cs * ce * 2,

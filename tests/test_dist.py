@@ -71,3 +71,75 @@ def test_shard_range_partitions_exactly():
     # the reference's round-robin rule (tests/sagemaker_launcher/test_launch_processing.py:20-36)
     assert chunk_items(list(range(7)), 3) == [[0, 3, 6], [1, 4], [2, 5]]
     assert chunk_items([1, 2], 5) == [[1], [2]]
+
+
+def _run_bench(args, extra_env=None):
+    import subprocess
+    import sys
+    from pathlib import Path
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py")] + args,
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_invocation():
+    """`python bench.py --gpus 2` with no launcher (no WORLD_SIZE): the script starts the two ranks itself before touching
+    torch, rank 0's single JSON line comes through, exit status 0.  --dry-run swaps RCCL/GPU work for gloo + rank-tagged
+    blocks, so this is the launcher, rendezvous, timing and ragged-gather plumbing of the N > 1 path (the reference's
+    fan-out: scripts/launch_processing.py:59-66, 199-233)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["gather_ok"] is True and out["value"] is None
+    assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+
+
+def test_bench_self_launch_fails_when_a_rank_dies():
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0"], {"MMC_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert "rank 1 exited with status" in r.stderr
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r = _run_bench(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl_gather_is_in_patch_order():
+    """gather_features over RCCL with a ragged n_total, one rank per GPU -- needs two GPUs (the 1-GPU test box skips it; RCCL
+    refuses two ranks on one device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, col0 in results:
+        np.testing.assert_array_equal(col0, np.arange(11))
+
+
+def _nccl_worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from mermaid_classifier_amd.dist import gather_features, shard_range
+        lo, hi = shard_range(n_total, rank, world)
+        local = torch.arange(lo, hi, dtype=torch.float32, device="cuda").view(-1, 1).repeat(1, 4)
+        out = gather_features(local, n_total)
+        q.put((rank, out[:, 0].cpu().numpy()))
+    finally:
+        dist.destroy_process_group()

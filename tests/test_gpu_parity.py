@@ -143,11 +143,37 @@ def test_extractor_contract_and_image_path(checkpoint_path, oracle_net, golden_b
     want = golden_backbone["image_features"]
     assert features.npoints == len(rowcols) and features.feature_dim == 1280 and msg.runtime > 0
     assert cosine(got, want).min() >= COS_GATE and rel_l2(got, want).max() < TOL_NOISE
-    # the reference's own gate, with the oracle as the CPU side
-    mn, med, mx = verify_device_numerics(ex, lambda ps: ref.patches_to_features(oracle_net, np.stack(ps)))
-    assert mn >= COS_GATE
+    # the reference's own gate, with the oracle as the CPU side (reference signature; keyword-only substitute for pyspacer)
+    loc = DataLocation("filesystem", str(checkpoint_path))
+    assert verify_device_numerics(ex, loc, 10, "cuda",
+                                  cpu_features_fn=lambda ps: ref.patches_to_features(oracle_net, np.stack(ps))) is None
     with pytest.raises(ValueError):
         ex(Image.fromarray(image), [(700, 5)])
+
+
+def test_numerics_gate_against_stock_cpu_path(checkpoint_path, caplog):
+    """scripts/build_feature_bucket.py:854-861 unmodified: the class factory's product on the GPU, then
+    ``verify_device_numerics(extractor, weights_loc, batch_size, device)`` -- whose CPU side is ``cls(device="cpu")`` from
+    the same factory, i.e. pyspacer's own torch-CPU path (a stand-in pyspacer backed by the oracle is installed)."""
+    import logging
+    import fake_spacer
+    from mermaid_classifier_amd import build_extractor_class, verify_device_numerics
+    from mermaid_classifier_amd.spacer_shim import DataLocation
+    loc = DataLocation("filesystem", str(checkpoint_path))
+    with fake_spacer.installed() as Base:
+        cls = build_extractor_class()
+        assert issubclass(cls, Base)
+        extractor = cls(data_locations={"weights": loc}, device="cuda", batch_size=10)
+        with caplog.at_level(logging.INFO, logger="mermaid_classifier_amd.extractor"):
+            assert verify_device_numerics(extractor, loc, 10, "cuda") is None
+        print(caplog.text)
+        assert "min_cos=0.9999" in caplog.text
+        # pyspacer's __call__ (CPU crop, PIL patches) feeding the HIP patches_to_features
+        rng = np.random.default_rng(5)
+        image = rng.integers(0, 255, (500, 640, 3), dtype=np.uint8)
+        feats, _ = extractor(image, [(10, 20), (250, 320)])
+        assert feats.npoints == 2 and len(feats.point_features[0].data) == 1280
+        extractor._cached_net.close()
 
 
 def test_crop_kernel_matches_oracle_bitwise():

@@ -244,3 +244,50 @@ def test_check_extract_inputs():
         check_extract_inputs(img, [(300, 0)])
     with pytest.raises(ValueError, match="exceed"):
         check_extract_inputs(np.zeros((200, 400, 3), np.uint8), [(1, 1)])
+
+
+def test_numerics_gate_runs_as_the_reference_calls_it(checkpoint_path, oracle_net, caplog):
+    """scripts/build_feature_bucket.py:860-861 calls ``verify_device_numerics(extractor, weights_loc, batch_size, device)``
+    and the gate builds its CPU side with ``cls(..., device="cpu")`` from the replaced class factory (:475-480).  With a
+    stand-in pyspacer installed, that whole sequence runs unmodified: the cpu-side instance takes pyspacer's own torch path
+    (load_weights -> to(cpu) -> eval -> transformation -> extract_features), the gate logs and returns None, raises on a
+    mismatch, and is a no-op for device == "cpu".  (The device side is a stub here: no GPU in the CPU suite; the -m gpu test
+    test_numerics_gate_against_stock_cpu_path runs the same sequence against the HIP extractor.)"""
+    import logging
+    import fake_spacer
+    from mermaid_classifier_amd import build_extractor_class, verify_device_numerics
+    from mermaid_classifier_amd.spacer_shim import DataLocation
+    from oracle import efficientnet_b0_ref as ref
+    loc = DataLocation("filesystem", str(checkpoint_path))
+    with fake_spacer.installed() as Base:
+        cls = build_extractor_class()
+        assert issubclass(cls, Base)
+        cpu_ex = cls(data_locations={"weights": loc}, device="cpu", batch_size=3)
+        patches = ref.synthetic_patches(4, seed=42)
+        feats, remote = cpu_ex.patches_to_features(list(patches))
+        assert remote is False and cpu_ex._cached_net.device == "cpu" and cpu_ex._cached_net.evaluated
+        want = ref.patches_to_features(oracle_net, patches)
+        np.testing.assert_allclose(np.asarray(feats), want, rtol=0, atol=5e-5)   # the CPU arithmetic in batches of 3 (conv summation order varies with the batch)
+        assert cpu_ex.patches_to_features(list(patches[:1]))[1] is False            # cached net: loaded_remote only once
+
+        class DeviceStub:   # stands for the HIP extractor: features a hair away from / far away from the CPU side
+            def __init__(self, scramble):
+                self.scramble = scramble
+
+            def patches_to_features(self, ps):
+                f = ref.patches_to_features(oracle_net, np.stack([np.asarray(p) for p in ps]))
+                f = f * (1 + 1e-4 * np.sin(np.arange(f.shape[1]))).astype(np.float32)
+                return (f[:, ::-1] if self.scramble else f).tolist(), False
+
+        with caplog.at_level(logging.INFO, logger="mermaid_classifier_amd.extractor"):
+            assert verify_device_numerics(DeviceStub(False), loc, 4, "cuda") is None      # positional, as the reference calls it
+        assert "Device numerics check (cuda vs cpu, 8 random patches): min_cos=" in caplog.text
+        with pytest.raises(RuntimeError, match="Device numerics check FAILED on cuda"):
+            verify_device_numerics(DeviceStub(True), loc, 4, "cuda")
+        assert verify_device_numerics(None, None, 4, "cpu") is None                       # :459-460
+    # without pyspacer there is no CPU side to build: loud, not a fallback
+    cls = build_extractor_class()
+    with pytest.raises(RuntimeError, match="needs pyspacer"):
+        cls(data_locations={"weights": loc}, device="cpu", batch_size=3)
+    with pytest.raises(RuntimeError, match="needs pyspacer"):
+        verify_device_numerics(object(), loc, 4, "cuda")
