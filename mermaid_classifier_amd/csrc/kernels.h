@@ -75,6 +75,8 @@ struct TailArgs {
     _Float16* dbg_dw;       // optional [B][49][1152]: depthwise output of the last block run (nblk == 1)
     float* dbg_gate;        // optional [B][1152] (or [B][672] for the pre-block)
     float* dbg_clk;         // optional [B][8]: shader cycles per phase (expand, dw, fc1, fc2, gate, project)
+    int clk_sections;       // 0: dbg_clk is [B][8] (one block per launch); 1: [B][8 sections][8] -- section 0 = block 11 (front half, SE,
+                            // gate, project), 1..4 = blocks 12..15 (expand, dw, fc1, fc2, gate, project), 5 = head, 6 = whole kernel
     // optional pre-block: second half of block 11 (squeeze-excite + project 672 -> 192, no skip) on its depthwise output
     const _Float16* pre_D;      // [B][49][672] or null
     const float* pre_pool;      // [B][672] pool sums (one tile per patch)
@@ -96,6 +98,7 @@ struct TailArgs {
     float* feat;                // [B][1280]
     float inv_hw;               // 1 / (49 log2 e)
     int in_wide;                // input X is [B][49][320] (head-only launches)
+    int tune[4];                // experiment knobs (env MMC_T7_TUNE0..3, read by launch_tail7); 0 = off
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 

@@ -36,6 +36,28 @@ static __device__ __forceinline__ float silu_scaled(float t)
     return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
+// Pins the loads written before it where they are written: nothing is scheduled across.  hipcc's scheduler otherwise sinks
+// a prefetch down to its first use, i.e. turns it into a plain load.  (A mask that lets ALU / MFMA / LDS instructions cross,
+// 0x78F, was measured far worse: tail7's project 12 k -> 23 k cycles, head 28 k -> 55 k -- the loads moved again.)
+#define PIN_VMEM() __builtin_amdgcn_sched_barrier(0)
+
+// The same on N accumulators at once, stage by stage (all exponentials, all adds, all reciprocals, all products): element by
+// element the four-instruction chain exp -> add -> rcp -> mul stalls on each transcendental's latency (the compiler pads it
+// with s_nop); staged, every instruction has N - 1 independent ones between it and its consumer.  Same values, bit for bit.
+template <int N>
+static __device__ __forceinline__ void silu_scaled_staged(float (&t)[N])
+{
+    float e[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_exp2f(-t[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = 1.0f + e[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = t[i] * e[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stem: u8 HWC patch -> conv3x3 stride 2 (TF-same: pad right/bottom by 1) -> +bias -> SiLU -> fp16
 // One workgroup = 16x16 output pixels of one patch; wave w owns output rows 4w..4w+3, one MFMA
@@ -1649,6 +1671,9 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
     float* rs = reinterpret_cast<float*>(smem + T7_OFF_RS);
     const int tid0 = threadIdx.x;
     const int b = blockIdx.x;
+    const bool clk_on = a.dbg_clk && a.clk_sections;
+    long long tkk[6] = {0, 0, 0, 0, 0, 0};   // whole-kernel stamps (production-mode phase clock, MMC_TAIL_CLK=1)
+    if (clk_on) tkk[0] = (long long)__builtin_readcyclecounter();
     // ---- project conv pieces shared by the block loop and the b11 pre-block --------------------------------------
     // Output fragments (16 channels) nf0 .. nf0+nfn-1 of this wave; weight image [cout/16][KS][64 lanes][16 B].
     auto proj_prefetch = [&](const GLOBAL_AS _Float16* wproj, const GLOBAL_AS float* bproj, int KS, int nf0, int nfn, int lane, int q,
@@ -1675,39 +1700,73 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         const unsigned char* bxp[4];
 #pragma unroll
         for (int pf = 0; pf < 4; ++pf) bxp[pf] = ED + pixc[pf] * es + 16 * q;
-        // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside one
-        auto k_loop = [&](auto nf_tag) {
-            constexpr int NF = decltype(nf_tag)::value;
-            h8 bx[4], bn[4];
+        // NF = output fragments of this wave: straight-line loops per NF instead of wave-uniform branches inside one.
+        // Weight fragments live in TWO register sets of four k-steps each: while the MFMAs of one set run, the other set
+        // is refilled for four k-steps later, in consumption order.  (With one set refilled in place inside a rolled loop
+        // the compiler loaded into temporaries and copied them back at the loop end behind an s_waitcnt vmcnt(0): the
+        // four-k-step prefetch distance collapsed to half an iteration and every iteration exposed an L2 round trip.)
+        auto k_loop = [&](auto nf_tag, auto ks_tag) {
+            constexpr int NF = decltype(nf_tag)::value, KSC = decltype(ks_tag)::value;
+            static_assert(KSC % 4 == 0 && KSC >= 8, "k-steps come in sets of four");
+            h8 bx[4], bn[4], wb[NF][4];
 #pragma unroll
             for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf]);
+            auto step = [&](int ks, const h8 (&wset)[3][4], int d) {
+                const int kn = ks + 1 < KSC ? ks + 1 : KSC - 1;   // last step re-reads itself (unused)
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wset[i][d], bx[pf], acc[i][pf], 0, 0, 0);
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+            };
+            auto stepb = [&](int ks, int d) {
+                const int kn = ks + 1 < KSC ? ks + 1 : KSC - 1;
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[i][d], bx[pf], acc[i][pf], 0, 0, 0);
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+            };
 #pragma unroll 1
-            for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+            for (int k0 = 0; k0 + 8 <= KSC; k0 += 8) {
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int ks = ks0 + d;
-                    const int kn = ks + 1 < KS ? ks + 1 : KS - 1;   // last step re-reads itself (unused)
+                for (int d = 0; d < 4; ++d) {     // set A computes, set B is requested for k0+4 .. k0+7
 #pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
-                    h8 w[NF];
+                    for (int i = 0; i < NF; ++i) wb[i][d] = gload<h8>(wproj, wo[i] + (unsigned)((k0 + 4 + d) * 1024));
+                    PIN_VMEM();   // the request stays HERE: the scheduler otherwise sinks it next to its use
+                    step(k0 + d, wa, d);
+                    PIN_VMEM();
+                }
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) w[i] = wa[i][d];
-                    const int kw = ks + 4 < KS ? ks + 4 : KS - 1;   // the last four prefetches re-read the last step (unused)
+                for (int d = 0; d < 4; ++d) {     // set B computes, set A is requested for k0+8 .. k0+11 (clamped: unused past the end)
+                    const int kw = k0 + 8 + d < KSC ? k0 + 8 + d : KSC - 1;
 #pragma unroll
                     for (int i = 0; i < NF; ++i) wa[i][d] = gload<h8>(wproj, wo[i] + (unsigned)(kw * 1024));
-#pragma unroll
-                    for (int i = 0; i < NF; ++i)
-#pragma unroll
-                        for (int pf = 0; pf < 4; ++pf)
-                            acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[i], bx[pf], acc[i][pf], 0, 0, 0);
-#pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+                    PIN_VMEM();
+                    stepb(k0 + 4 + d, d);
+                    PIN_VMEM();
                 }
             }
+            if (KSC % 8) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) step(KSC - 4 + d, wa, d);
+            }
         };
-        if (nfn == 3) k_loop(std::integral_constant<int, 3>{});
-        else if (nfn == 2) k_loop(std::integral_constant<int, 2>{});
-        else k_loop(std::integral_constant<int, 1>{});
+        auto run_nf = [&](auto ks_tag) {
+            if (nfn == 3) k_loop(std::integral_constant<int, 3>{}, ks_tag);
+            else if (nfn == 2) k_loop(std::integral_constant<int, 2>{}, ks_tag);
+            else k_loop(std::integral_constant<int, 1>{}, ks_tag);
+        };
+        if (KS == 36) run_nf(std::integral_constant<int, 36>{});
+        else run_nf(std::integral_constant<int, 24>{});
         if (mode == 1) {   // b15: the result replaces ED (all reads of ED are done after the barrier)
             T7_BAR();
 #pragma unroll
@@ -1798,9 +1857,58 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
             const int band = tid / CH, cd = tid - band * CH;
             const bool dw_thr = tid < 4 * CH;
-            h8 wn[4];   // weight fragments one ahead -- across the chunk boundary too (fragment 42 = fragment 41 re-read, unused)
+            // Weight fragments AND the bias of the next output fragment are requested one fragment ahead (across the chunk
+            // boundary too; fragment 42 = fragment 41 re-read, unused), bias first: a load needed now is never queued behind
+            // loads needed later (vmcnt retires in order).  The wave's role (two pixel fragments or one) is a template argument
+            // and lanes past pixel 195 store to a scratch word instead of branching, so a chunk's expand is one straight-line
+            // block: requests pinned at the top of each fragment, SiLU staged over the fragment's 4 or 8 accumulators.
+            h8 wn[4];
+            float bsn = gload<float>(bexp, (unsigned)m * 4u);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((ks * 64 + lane) * 16));
+            unsigned char* const scratch = reinterpret_cast<unsigned char*>(part) + 2048 + lane * 4;   // beyond pband, unread
+            auto expand_chunk = [&](auto npf_tag, int chunk) {
+                constexpr int NPF = decltype(npf_tag)::value;
+#pragma unroll
+                for (int nf = 0; nf < 6; ++nf) {
+                    const int nfg = 6 * chunk + nf;
+                    h8 wc[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
+                    const float bs = bsn;
+                    {
+                        const int nxt = nfg + 1 < 42 ? nfg + 1 : 41;
+                        bsn = gload<float>(bexp, (unsigned)(16 * nxt + m) * 4u);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)(((nxt * 4 + ks) * 64 + lane) * 16));
+                    }
+                    PIN_VMEM();
+                    const f4 bv = {bs, bs, bs, bs};
+                    f4 acc[NPF];
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) acc[i] = bv;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)   // un-swapped: lane (m, q) = channel 16 nf + m of pixels 16 pf + 4q .. +3
+#pragma unroll
+                        for (int i = 0; i < NPF; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[i][ks], wc[ks], acc[i], 0, 0, 0);
+                    float t[4 * NPF];
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[4 * i + j] = acc[i][j];
+                    silu_scaled_staged(t);
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int pix0 = 16 * (pf0 + i) + 4 * q;
+                        const h2 p0 = {(_Float16)t[4 * i], (_Float16)t[4 * i + 1]};
+                        const h2 p1 = {(_Float16)t[4 * i + 2], (_Float16)t[4 * i + 3]};
+                        const bool ok = pix0 < 196;
+                        unsigned char* dst = EB + (pix0 >> 1) * ES2 + (16 * nf + m) * 4;
+                        *reinterpret_cast<h2*>(ok ? dst : scratch) = p0;
+                        *reinterpret_cast<h2*>(ok ? dst + ES2 : scratch + 256) = p1;
+                    }
+                }
+            };
 #pragma unroll 1
             for (int chunk = 0; chunk < 7; ++chunk) {
                 uint32_t raw[15];
@@ -1808,39 +1916,8 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll
                 for (int i = 0; i < 15; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * 672 + cg) * 4u);
                 const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
-                {
-#pragma unroll
-                    for (int nf = 0; nf < 6; ++nf) {
-                        const int nfg = 6 * chunk + nf;
-                        h8 wc[4];
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) wc[ks] = wn[ks];
-                        {
-                            const int nxt = nfg + 1 < 42 ? nfg + 1 : 41;
-#pragma unroll
-                            for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)(((nxt * 4 + ks) * 64 + lane) * 16));
-                        }
-                        const float bs = gload<float>(bexp, (unsigned)(16 * nfg + m) * 4u);
-                        const f4 bv = {bs, bs, bs, bs};
-                        f4 acc[2] = {bv, bv};
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {   // un-swapped: lane (m, q) = channel 16 nf + m of pixels 16 pf + 4q .. +3
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0][ks], wc[ks], acc[0], 0, 0, 0);
-                            if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[1][ks], wc[ks], acc[1], 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const int pix0 = 16 * (pf0 + i) + 4 * q;
-                            if (i < npf && pix0 < 196) {
-                                h2 p0 = {(_Float16)silu_scaled(acc[i][0]), (_Float16)silu_scaled(acc[i][1])};
-                                h2 p1 = {(_Float16)silu_scaled(acc[i][2]), (_Float16)silu_scaled(acc[i][3])};
-                                unsigned char* dst = EB + (pix0 >> 1) * ES2 + (16 * nf + m) * 4;
-                                *reinterpret_cast<h2*>(dst) = p0;
-                                *reinterpret_cast<h2*>(dst + ES2) = p1;
-                            }
-                        }
-                    }
-                }
+                if (npf == 2) expand_chunk(std::integral_constant<int, 2>{}, chunk);
+                else expand_chunk(std::integral_constant<int, 1>{}, chunk);
                 T7_BAR();
                 float psum = 0.f;
                 {
@@ -1878,11 +1955,11 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                                                                          *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
                                     }
                             }
+                            silu_scaled_staged(acc);
 #pragma unroll
                             for (int ox = 0; ox < 7; ++ox) {
-                                const float y = silu_scaled(acc[ox]);
-                                psum += y;
-                                if (dw_thr) *reinterpret_cast<_Float16*>(ED + (oy * 7 + ox) * T7_DS11 + (chunk * CH + cd) * 2) = (_Float16)y;
+                                psum += acc[ox];
+                                if (dw_thr) *reinterpret_cast<_Float16*>(ED + (oy * 7 + ox) * T7_DS11 + (chunk * CH + cd) * 2) = (_Float16)acc[ox];
                             }
                         }
                     }
@@ -1909,6 +1986,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int kk = tid; kk < 672; kk += 512) pooled[kk] = a.pre_pool[(size_t)b * 672 + kk];
         }
         T7_BAR();
+        if (clk_on) tkk[1] = (long long)__builtin_readcyclecounter();
         if (fc_thr) {
             f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1957,6 +2035,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         h8 wa[3][4];
         proj_prefetch(wproj, bproj, 24, nf0, nfn, lane, q, pbias, wo, wa);
         T7_BAR();
+        if (clk_on) tkk[2] = (long long)__builtin_readcyclecounter();
         for (int e = tid; e < T7_PIX * 84; e += 512) {
             const int pix = e / 84, oc = e - pix * 84;
             uint4* pv = reinterpret_cast<uint4*>(ED + pix * DS + oc * 16);
@@ -1965,8 +2044,13 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             *pv = gate_h8(*pv, g0, g1);
         }
         T7_BAR();
+        if (clk_on) tkk[3] = (long long)__builtin_readcyclecounter();
         proj_run(wproj, 24, 2, nf0, nfn, lane, m, q, pixc, pbias, wo, wa, DS);
         T7_BAR();
+        if (clk_on) {
+            tkk[4] = (long long)__builtin_readcyclecounter();
+            if (tid0 == 0) for (int i = 0; i < 4; ++i) a.dbg_clk[((size_t)b * 8) * 8 + i] = (float)(tkk[i + 1] - tkk[i]);
+        }
     } else if (a.in_wide) {
         // head-only use (per-tensor tests): the input is block 15's output [49][320]
         const int tid = tid0;
@@ -2034,38 +2118,62 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             // Every workgroup streams the same weights at about the same time; rotating the fragment order by
             // workgroup spreads the requests of the CUs that share an L2 over its channels.
             const int rot = (b >> 3) % 9;
+            // The weight fragments AND the bias of the next output fragment are requested one fragment ahead, bias first:
+            // vmcnt retires in order, so a load that is needed now must never be issued behind loads that are needed later
+            // (a bias load issued after the prefetch made every iteration wait for the whole prefetch: s_waitcnt vmcnt(0)).
+            // Fully unrolled: no loop-carried register rotation (copies + waits at the loop end), and the scheduler may put
+            // fragment i's SiLU epilogue between the MFMAs of fragment i+1.
             h8 wn[6];
+            f4 bvn = gload<f4>(W.bexp, (unsigned)(16 * (9 * wave + rot) + 4 * q) * 4u);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)((((9 * wave + rot) * 6 + ks) * 64 + lane) * 16));
-#pragma unroll 1
+#pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int ir = i + rot >= 9 ? i + rot - 9 : i + rot;
                 const int nf = 9 * wave + ir;
                 h8 wc[6];
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
+                const f4 bv = bvn;
                 if (i + 1 < 9) {
                     const int nfn = 9 * wave + (ir + 1 >= 9 ? ir + 1 - 9 : ir + 1);
+                    bvn = gload<f4>(W.bexp, (unsigned)(16 * nfn + 4 * q) * 4u);
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)(((nfn * 6 + ks) * 64 + lane) * 16));
                 }
-                const f4 bv = gload<f4>(W.bexp, (unsigned)(16 * nf + 4 * q) * 4u);
                 f4 acc[4];
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
+                long long st0 = 0, st1 = 0, st2 = 0;   // diagnostic stamps of fragment 4 (clock build only)
+                if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st0 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
                 for (int ks = 0; ks < 6; ++ks)
 #pragma unroll
                     for (int pf = 0; pf < 4; ++pf)
                         acc[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[pf][ks], acc[pf], 0, 0, 0);
+                if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st1 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+                {
+                    float t[16];
 #pragma unroll
-                for (int pf = 0; pf < 4; ++pf) {
-                    if (16 * pf + m < T7_PIX) {
-                        h4 o;
+                    for (int pf = 0; pf < 4; ++pf)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (_Float16)silu_scaled(acc[pf][j]);
-                        *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_ES + (16 * nf + 4 * q) * 2) = o;
+                        for (int j = 0; j < 4; ++j) t[4 * pf + j] = acc[pf][j];
+                    silu_scaled_staged(t);
+                    if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st2 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf) {
+                        if (16 * pf + m < T7_PIX) {
+                            h4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (_Float16)t[4 * pf + j];
+                            *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_ES + (16 * nf + 4 * q) * 2) = o;
+                        }
                     }
+                }
+                if (i == 4 && clk_on && nb == 1 && lane == 0 && (wave == 0 || wave == 4)) {
+                    const long long st3 = (long long)__builtin_readcyclecounter();
+                    float* dst = a.dbg_clk + ((size_t)b * 8 + 7) * 8 + (wave ? 4 : 0);
+                    dst[0] = (float)(st1 - st0); dst[1] = (float)(st2 - st1); dst[2] = (float)(st3 - st2); dst[3] = (float)(st0 - tk[0]);
                 }
             }
         }
@@ -2079,6 +2187,10 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         const bool fc1_thr = tid < 384;
         const int cr = tid / 12, j4 = tid - cr * 12;   // FC1: thread = 4 outputs j x channels cr, cr+32, ...
         u2v fw1[36];   // 4 fp16 weights each, consumed by v_fma_mix_f32 without conversion
+        u2v fw2[48];   // excite FC: thread = 4 consecutive channels x all 48 squeeze units
+        const bool fc2_thr = tid < 288;
+        const int t2 = fc2_thr ? tid : 0;
+        float brv = 0.f;
         auto dw_phase = [&](auto ks_tag) {
             constexpr int KS = decltype(ks_tag)::value, R = KS / 2, NP = KS == 5 ? 3 : 2;
             auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[2 * KS * NP]) {
@@ -2149,7 +2261,13 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
                 pooled[c] = psum;
             };
-            // taps of the next round are requested before the current round computes
+            // The depthwise phase is VALU / LDS work with the vector-memory path idle: everything the next phases stream is
+            // requested here, in the order it will be consumed, and PINNED (sched_barrier) -- left alone the scheduler sinks
+            // each request to just before its first use, which put the whole squeeze-excite weight fetch (221 KB per
+            // block) on the critical path of the two FCs.  Taps of the next round before the current round computes; the
+            // squeeze FC weights (36 x 8 bytes per thread) and the first half of the excite FC weights (24 x 8 bytes) before
+            // the last quarter round (earlier the two tap buffers leave no registers for them: spills); the second half
+            // once FC1 has consumed the squeeze weights.
 #pragma unroll
             for (int i = 0; i < 3 * KS; ++i) rawB[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 512 + tid) * 4u);
             biasB = gload<float>(W.bdw, (unsigned)(512 + tid) * 4u);
@@ -2159,13 +2277,15 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int i = 0; i < 3 * KS; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 1024 + cl) * 4u);
             biasA = gload<float>(W.bdw, (unsigned)(1024 + cl) * 4u);
             dw_round(512 + tid, rawB, biasB);
-            // Squeeze FC weights (fp16, 36 x 8 bytes per thread): requested before the last quarter round, which is
-            // pure VALU/LDS work (earlier the two tap buffers leave no registers for them).
             {
                 const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)
 #pragma unroll
                 for (int i = 0; i < 36; ++i) fw1[i] = gload<u2v>(W.wr_t, (unsigned)(((32 * i + crl) * 48 + 4 * j4) * 2));
             }
+#pragma unroll
+            for (int k = 0; k < 24; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
+            brv = tid < 48 ? gload<float>(W.br, (unsigned)tid * 4u) : 0.f;
+            PIN_VMEM();
             {
                 // Channels 1024..1151 (a quarter round) are shared by FOUR threads each so that all 8 waves stay busy:
                 // thread (channel, p) computes output rows 2p and 2p+1 from input rows 2p-R .. 2p+1+R (zeros outside
@@ -2237,8 +2357,6 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // ---------------- squeeze-excite FC1: r = silu(br + pooled . Wr^T) ----------------
         // One patch per workgroup makes the two FCs matrix-VECTOR products: fp32 FMAs on fp16 weights (fixed
         // summation order).  The excite weights (48 x 8 bytes per thread) are requested before FC1 computes.
-        const bool fc2_thr = tid < 288;   // FC2: thread = 4 consecutive channels
-        const float brv = tid < 48 ? gload<float>(W.br, (unsigned)tid * 4u) : 0.f;
         if (fc1_thr) {
             f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -2251,16 +2369,19 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
             *reinterpret_cast<f4*>(part + cr * 48 + 4 * j4) = acc;
         }
-        u2v fw2[48];
-        const int t2 = fc2_thr ? tid : 0;
+        PIN_VMEM();
 #pragma unroll
-        for (int k = 0; k < 48; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
+        for (int k = 24; k < 48; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
         const f4 bev = gload<f4>(W.be, (unsigned)t2 * 16u);
+        PIN_VMEM();
         T7_BAR();
         if (tid < 48) {
+            float pv[32];   // all 32 partials requested at once (one LDS latency, not 32), summed in the fixed order
+#pragma unroll
+            for (int w = 0; w < 32; ++w) pv[w] = part[w * 48 + tid];
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 32; ++w) s += part[w * 48 + tid];
+            for (int w = 0; w < 32; ++w) s += pv[w];
             // the pooled sums are over 49 pixels of log2(e)-scaled activations (kept out of the fp16 weights)
             rs[tid] = silu_f(s * (float)(1.0 / (49.0 * 1.4426950408889634)) + brv);
         }
@@ -2315,9 +2436,11 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         T7_TICK();
 #undef T7_TICK
         if (a.dbg_clk && tid0 == 0) {   // cycles per phase of this block: expand, dw, fc1, fc2, gate, project
-            for (int i = 0; i < 6; ++i) a.dbg_clk[(size_t)b * 8 + i] = (float)(tk[i + 1] - tk[i]);
+            float* dst = a.clk_sections ? a.dbg_clk + ((size_t)b * 8 + 1 + nb) * 8 : a.dbg_clk + (size_t)b * 8;
+            for (int i = 0; i < 6; ++i) dst[i] = (float)(tk[i + 1] - tk[i]);
         }
     }
+    if (clk_on) tkk[5] = (long long)__builtin_readcyclecounter();
     if (a.head_w) {
         // ---- head: features[n] = mean over pixels of silu(b[n] + Y15[pixel] . Wh[n]) (1280 x 320), Y15 in ED [49][320].
         //      Wave w owns output fragments 10w .. 10w+9 in two groups of five (accumulators 5 x 4 pixel fragments);
@@ -2333,19 +2456,27 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         for (int g = 0; g < 2; ++g) {
             const int nfb = 10 * wave + 5 * g;
             f4 acc[5][4];
-            h8 wc[5], wn[5];
+            // Weight fragments of a k-step live in one of three register sets, requested TWO k-steps ahead in consumption
+            // order; the k loop is straight-line (no register rotation) and the requests are pinned where they are written
+            // (left alone, the scheduler sinks each load next to its first use: one exposed L2 round trip per k-step).
+            h8 w[3][5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const f4 bv = gload<f4>(hb, (unsigned)(16 * (nfb + i) + 4 * q) * 4u);
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) acc[i][pf] = bv;
-                wc[i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10) * 64 + lane) * 16));
             }
-#pragma unroll 2
-            for (int ks = 0; ks < 10; ++ks) {
-                const int kn = ks + 1 < 10 ? ks + 1 : 9;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) wn[i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10 + kn) * 64 + lane) * 16));
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 5; ++i) w[s2][i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10 + s2) * 64 + lane) * 16));
+#pragma unroll
+            for (int ks = 0; ks < 10; ++ks) {
+                if (ks + 2 < 10) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) w[(ks + 2) % 3][i] = gload<h8>(hw, (unsigned)((((nfb + i) * 10 + ks + 2) * 64 + lane) * 16));
+                }
+                PIN_VMEM();
                 h8 bx[4];
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * ks);
@@ -2353,18 +2484,23 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int pf = 0; pf < 4; ++pf)
-                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], bx[pf], acc[i][pf], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) wc[i] = wn[i];
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[ks % 3][i], bx[pf], acc[i][pf], 0, 0, 0);
+                PIN_VMEM();
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
+                float t[16];
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[4 * pf + j] = acc[i][pf][j];
+                silu_scaled_staged(t);
                 f4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) {
                     const bool ok = 16 * pf + m < T7_PIX;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[j] += ok ? silu_scaled(acc[i][pf][j]) : 0.f;
+                    for (int j = 0; j < 4; ++j) sum[j] += ok ? t[4 * pf + j] : 0.f;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2377,6 +2513,11 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
                 if (m == 0) *reinterpret_cast<f4*>(a.feat + (size_t)b * 1280 + 16 * (nfb + i) + 4 * q) = sum;
             }
+        }
+        if (clk_on && tid0 == 0) {
+            const long long tend = (long long)__builtin_readcyclecounter();
+            a.dbg_clk[((size_t)b * 8 + 5) * 8] = (float)(tend - tkk[5]);
+            a.dbg_clk[((size_t)b * 8 + 6) * 8] = (float)(tend - tkk[0]);
         }
     } else if (!out_wide) {
         const int tid = tid0;
@@ -2469,41 +2610,59 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
             }
         }
     }
+            // Weight fragments and bias of the next 16-channel fragment are requested one fragment ahead, bias first and pinned
+            // (see tail7_kernel's block 11): the wave's role is a template argument and lanes past the last pixel store to a
+            // scratch word, so the six fragments of a chunk are one straight-line block.
             h8 wn[CKS];
+            float bsn = gload<float>(bexp, (unsigned)(16 * (6 * chunk) + m) * 4u);
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((6 * chunk) * CKS + ks) * 64 + lane) * 16));
+            unsigned char* const scratch = reinterpret_cast<unsigned char*>(pband + NBAND * CH) + lane * 4;
+            auto expand_chunk = [&](auto npf_tag) {
+                constexpr int NPFW = decltype(npf_tag)::value;
 #pragma unroll
-            for (int nf = 0; nf < 6; ++nf) {
-                const int nfg = 6 * chunk + nf;
-                h8 wc[CKS];
+                for (int nf = 0; nf < 6; ++nf) {
+                    const int nfg = 6 * chunk + nf;
+                    h8 wc[CKS];
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) wc[ks] = wn[ks];
-                if (nf + 1 < 6) {
+                    for (int ks = 0; ks < CKS; ++ks) wc[ks] = wn[ks];
+                    const float bs = bsn;
+                    if (nf + 1 < 6) {
+                        bsn = gload<float>(bexp, (unsigned)(16 * (nfg + 1) + m) * 4u);
 #pragma unroll
-                    for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((nfg + 1) * CKS + ks) * 64 + lane) * 16));
-                }
-                // un-swapped MFMA (pixels = rows, channels = columns): lane (m, q) gets channel 16 nf + m of pixels
-                // 16 pf + 4q .. +3 = two ready-made pixel pairs (same dot products, same k order as the swapped form)
-                const float bs = gload<float>(bexp, (unsigned)(16 * nfg + m) * 4u);
-                const f4 bv = {bs, bs, bs, bs};
-                f4 acc[2] = {bv, bv};
+                        for (int ks = 0; ks < CKS; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((((nfg + 1) * CKS + ks) * 64 + lane) * 16));
+                    }
+                    PIN_VMEM();
+                    // un-swapped MFMA (pixels = rows, channels = columns): lane (m, q) gets channel 16 nf + m of pixels
+                    // 16 pf + 4q .. +3 = two ready-made pixel pairs (same dot products, same k order as the swapped form)
+                    const f4 bv = {bs, bs, bs, bs};
+                    f4 acc[NPFW];
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0][ks], wc[ks], acc[0], 0, 0, 0);
-                    if (npf == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[1][ks], wc[ks], acc[1], 0, 0, 0);
-                }
+                    for (int i = 0; i < NPFW; ++i) acc[i] = bv;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pix0 = 16 * (pf0 + i) + 4 * q;
-                    if (i < npf && pix0 < HW) {
-                        h2 p0 = {(_Float16)silu_scaled(acc[i][0]), (_Float16)silu_scaled(acc[i][1])};
-                        h2 p1 = {(_Float16)silu_scaled(acc[i][2]), (_Float16)silu_scaled(acc[i][3])};
+                    for (int ks = 0; ks < CKS; ++ks)
+#pragma unroll
+                        for (int i = 0; i < NPFW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[i][ks], wc[ks], acc[i], 0, 0, 0);
+                    float t[4 * NPFW];
+#pragma unroll
+                    for (int i = 0; i < NPFW; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[4 * i + j] = acc[i][j];
+                    silu_scaled_staged(t);
+#pragma unroll
+                    for (int i = 0; i < NPFW; ++i) {
+                        const int pix0 = 16 * (pf0 + i) + 4 * q;
+                        const h2 p0 = {(_Float16)t[4 * i], (_Float16)t[4 * i + 1]};
+                        const h2 p1 = {(_Float16)t[4 * i + 2], (_Float16)t[4 * i + 3]};
+                        const bool ok = pix0 < HW;
                         unsigned char* dst = E + (pix0 >> 1) * ES2 + (16 * nf + m) * 4;
-                        *reinterpret_cast<h2*>(dst) = p0;
-                        *reinterpret_cast<h2*>(dst + ES2) = p1;
+                        *reinterpret_cast<h2*>(ok ? dst : scratch) = p0;
+                        *reinterpret_cast<h2*>(ok ? dst + ES2 : scratch + 256) = p1;
                     }
                 }
-            }
+            };
+            if (npf == 2) expand_chunk(std::integral_constant<int, 2>{});
+            else expand_chunk(std::integral_constant<int, 1>{});
         }
         T7_BAR();
         // ---------------- depthwise ----------------
@@ -2546,11 +2705,11 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                                                                      *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
                                 }
                         }
+                        silu_scaled_staged(acc);
 #pragma unroll
                         for (int ox = 0; ox < 7; ++ox) {
-                            const float y = silu_scaled(acc[ox]);
-                            psum += y;
-                            if (dw_thr) dg[(size_t)(oy * 7 + ox) * CE] = (_Float16)y;
+                            psum += acc[ox];
+                            if (dw_thr) dg[(size_t)(oy * 7 + ox) * CE] = (_Float16)acc[ox];
                         }
                     }
                 }
@@ -2586,11 +2745,11 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                                                                  *reinterpret_cast<const h2*>(&wq[ox & 1][ip]), acc[ox], false);
                             }
                     }
+                    silu_scaled_staged(acc);
 #pragma unroll
                     for (int ox = 0; ox < 14; ++ox) {
-                        const float y = silu_scaled(acc[ox]);
-                        psum += y;
-                        if (dw_thr) dg[(size_t)(oy * 14 + ox) * CE] = (_Float16)y;
+                        psum += acc[ox];
+                        if (dw_thr) dg[(size_t)(oy * 14 + ox) * CE] = (_Float16)acc[ox];
                     }
                 }
             }
@@ -3276,7 +3435,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
                 for (int nf = 0; nf < NF; ++nf) wnx[nf] = *reinterpret_cast<const h8*>(wl + ((nf * KS + kn) * 64 + lane) * 16);
                 const f4 gn0 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q);
                 const f4 gn1 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q + 4);
-                __builtin_amdgcn_sched_barrier(0);   // keep those reads AHEAD of this k-step's MFMAs (the scheduler sinks them otherwise)
+                PIN_VMEM();   // keep those reads AHEAD of this k-step's MFMAs (the scheduler sinks them otherwise)
                 h8 xb[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -3288,7 +3447,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
                     acc[0][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[nf], xb[0], acc[0][nf], 0, 0, 0);
                     acc[1][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wcur[nf], xb[1], acc[1][nf], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                PIN_VMEM();
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) wcur[nf] = wnx[nf];
                 gc0 = gn0;
@@ -3891,7 +4050,17 @@ int launch_tail7(const TailArgs& a, hipStream_t st)
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(tail7_kernel, dim3(a.B), dim3(512), T7_LDS, st, a);
+    static int tune[4] = {-1, -1, -1, -1};
+    if (tune[0] < 0)
+        for (int i = 0; i < 4; ++i) {
+            char nm[24];
+            snprintf(nm, sizeof nm, "MMC_T7_TUNE%d", i);
+            const char* e = getenv(nm);
+            tune[i] = e ? atoi(e) : 0;
+        }
+    TailArgs aa = a;
+    for (int i = 0; i < 4; ++i) aa.tune[i] = tune[i];
+    hipLaunchKernelGGL(tail7_kernel, dim3(a.B), dim3(512), T7_LDS, st, aa);
     LAUNCH_CHECK();
     return 0;
 }
@@ -3953,7 +4122,7 @@ int proj_patch_has(int K, int N, int HW, int res)
 template <int CKS, int KSD, int CE, int ST = 1>
 static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
 {
-    const int lds = 98 * 416 + 5 * 96 * 4;
+    const int lds = 98 * 416 + 5 * 96 * 4 + 512;   // E2 chunk, pool partials of the row bands, scratch words of the expand's masked stores
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE, ST>),

@@ -245,6 +245,7 @@ struct mmc_backbone {
     std::vector<void*> allocs;
     bool keep = false, fuse_stem = false;
     float* dbg_clk = nullptr;        // keep mode: per-patch phase cycle counts of the patch-resident kernels
+    float* tail_clk = nullptr;       // MMC_TAIL_CLK=1: [max_batch][8 sections][8] phase cycle counts of the production tail7 launch
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
     bool fuse_b0b1 = false;
@@ -424,6 +425,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     { const char* e = getenv("MMC_GRAPH"); bb->use_graph = !(e && e[0] == '0') && !bb->keep; }
     { const char* e = getenv("MMC_SE_SMALL"); bb->se_small = !(e && e[0] == '0'); }
     if (bb->keep) { int r__ = dev_alloc(bb, &bb->dbg_clk, (size_t)max_batch * 8); if (r__) { mmc_backbone_destroy(bb); return r__; } }
+    { const char* e = getenv("MMC_TAIL_CLK");
+      if (e && e[0] == '1' && !bb->keep) {
+          int r__ = dev_alloc(bb, &bb->tail_clk, (size_t)max_batch * 64); if (r__) { mmc_backbone_destroy(bb); return r__; }
+          hipMemset(bb->tail_clk, 0, (size_t)max_batch * 64 * sizeof(float));
+          bb->use_graph = false;
+      } }
     std::vector<uint64_t> table(2 * (size_t)nt);
     memcpy(table.data(), base + 16, (size_t)nt * 16);
     BlobReader rd{base, nbytes, nt, table.data()};
@@ -953,6 +960,9 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             ta.pre_wr_t = B.t_wr; ta.pre_br = B.pp_br; ta.pre_we_t = B.t_we; ta.pre_be = B.se_be; ta.pre_wproj = bb->pre_wproj;
             ta.pre_bproj = B.project.b; ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
             ta.head_w = bb->head_wfrag; ta.head_b = bb->head.b; ta.feat = out_dev;
+            if (bb->tail_clk) {   // debug clock: rows of this lane's patches (out_dev is the lane's slice of the caller's matrix)
+                ta.dbg_clk = bb->tail_clk + (size_t)(&ws - bb->lanes) * bb->lane_cap * 64; ta.clk_sections = 1;
+            }
             STEP("b11all-head.tail", "tail7", launch_tail7(ta, st));
             tail_done = true;
             break;
@@ -1267,6 +1277,15 @@ extern "C" int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, 
                                             size_t* n_written)
 {
     if (!bb || !name || !out) return fail(MMC_ERR_ARG, "NULL argument");
+    if (bb->tail_clk && strcmp(name, "tail.clk") == 0) {   // MMC_TAIL_CLK=1: phase clock of the last production pass
+        const size_t ne = (size_t)bb->max_batch * 64;
+        if (ne > capacity) return fail(MMC_ERR_ARG, "'tail.clk' has %zu elements, capacity %zu", ne, capacity);
+        HIP_TRY(hipSetDevice(bb->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, bb->tail_clk, ne * 4, hipMemcpyDeviceToHost));
+        if (n_written) *n_written = ne;
+        return MMC_OK;
+    }
     if (!bb->keep) return fail(MMC_ERR_ARG, "activations are not kept: set MMC_KEEP_ACTIVATIONS=1 before create");
     auto it = bb->saved.find(name);
     if (it == bb->saved.end()) return fail(MMC_ERR_ARG, "no saved activation named '%s'", name);

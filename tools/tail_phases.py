@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
-"""In-kernel phase timing of tail7_kernel (debug build path: MMC_KEEP_ACTIVATIONS=1 runs blocks 12..14 one
-launch each and records shader cycles per phase).  Development aid."""
+"""In-kernel phase timing of the PRODUCTION tail7 launch (block 11 .. features in one kernel, both lanes running):
+MMC_TAIL_CLK=1 makes the library hand tail7_kernel a clock buffer [patch][section][phase] (shader cycles, workgroup
+thread 0).  Sections: b11 (front half: expand + depthwise stride 2 | SE | gate | project), b12..b15 (expand | dw | fc1 |
+fc2 | gate | project), head, whole kernel.  Development aid.
+
+    python tools/tail_phases.py [batch]
+"""
 import os, sys
 from pathlib import Path
 import numpy as np
-os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
-os.environ.setdefault("MMC_LANES", "1")
+os.environ["MMC_TAIL_CLK"] = "1"
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     import torch
     from mermaid_classifier_amd.backbone import Backbone
     from mermaid_classifier_amd.synthetic import synthetic_state_dict
@@ -18,22 +22,19 @@ def main():
     bb = Backbone(sd, device=0, max_batch=n)
     p = torch.from_numpy(np.random.default_rng(42).integers(0, 255, (n, 224, 224, 3), dtype=np.uint8)).cuda()
     f = torch.empty((n, 1280), dtype=torch.float32, device="cuda")
-    for _ in range(3):
+    for _ in range(5):
         bb.extract(p, out=f)
     torch.cuda.synchronize()
+    clk = bb.read_activation("tail.clk", n * 64).reshape(n, 8, 8)
+    med = np.median(clk, axis=0)
+    print("tune", [os.environ.get(f"MMC_T7_TUNE{i}", "0") for i in range(4)])
+    print("b11 : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(["front", "se", "gate", "project"], med[0][:4])) + f"   total {med[0][:4].sum():8.0f}")
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
-    for blk in (12, 13, 14, 15):
-        clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :6]
-        med = np.median(clk, axis=0)
-        print(f"b{blk}: " + "  ".join(f"{nm} {c:8.0f}" for nm, c in zip(names, med)) + f"   total {med.sum():8.0f} cycles")
-    projse(bb, n)
-
-def projse(bb, n):
-    for blk in range(3, 11):
-        clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :8]
-        med = np.median(clk, axis=0)
-        print(f"b{blk}.projse: prologue {med[0]:8.0f}  gemm {med[1]:8.0f} cycles (wave 0, last pair: k-loop {med[2]:8.0f}); prologue barriers at " + " ".join(f"{v:.0f}" for v in med[3:8]))
-
+    for s in range(1, 5):
+        print(f"b{11 + s} : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(names, med[s][:6])) + f"   total {med[s][:6].sum():8.0f}")
+    print("b13 expand, fragment 4 of wave 0 / wave 4: " + " | ".join(
+        f"mfma {med[7][o]:5.0f} silu {med[7][o + 1]:5.0f} store {med[7][o + 2]:5.0f} (starts at {med[7][o + 3]:6.0f})" for o in (0, 4)))
+    print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
 
 if __name__ == "__main__":
     main()
