@@ -2117,63 +2117,82 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                     xb[pf][ks] = *reinterpret_cast<const h8*>(XL + pixc[pf] * T7_XS + (32 * ks + 8 * q) * 2);
             // Every workgroup streams the same weights at about the same time; rotating the fragment order by
             // workgroup spreads the requests of the CUs that share an L2 over its channels.
-            const int rot = (b >> 3) % 9;
+            // (No per-workgroup rotation of the fragment order: the loop is unrolled, and the compiler picks the fused or the two-step
+            // f32 -> f16 form of the last multiply per POSITION in it -- with a rotation the same channel came out in different last
+            // bits in different workgroups; measured, the rotation bought nothing.)
+            constexpr int rot = 0;
             // The weight fragments AND the bias of the next output fragment are requested one fragment ahead, bias first:
             // vmcnt retires in order, so a load that is needed now must never be issued behind loads that are needed later
             // (a bias load issued after the prefetch made every iteration wait for the whole prefetch: s_waitcnt vmcnt(0)).
-            // Fully unrolled: no loop-carried register rotation (copies + waits at the loop end), and the scheduler may put
-            // fragment i's SiLU epilogue between the MFMAs of fragment i+1.
+            //
+            // Software pipeline over the wave's nine output fragments: the 24 MFMAs of fragment i are interleaved, ONE MFMA
+            // then THREE vector instructions, with the SiLU epilogue of fragment i-1 (staged over its 16 accumulators: all
+            // exponentials, then all adds, all reciprocals, all products, then the packing and the four 8-byte LDS stores).
+            // Run back to back, a wave's MFMA burst holds the matrix pipe while its vector port idles and its SiLU burst the
+            // other way round, and the two waves of a SIMD do so in lockstep (measured: 384 cycles of MFMAs then ~800 of
+            // epilogue per fragment and wave, strictly one after the other).  An MFMA occupies the issue port for 8 of its
+            // 16 pipe cycles: three vector instructions fit in its shadow.  Same instructions, same values, other order.
             h8 wn[6];
             f4 bvn = gload<f4>(W.bexp, (unsigned)(16 * (9 * wave + rot) + 4 * q) * 4u);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)((((9 * wave + rot) * 6 + ks) * 64 + lane) * 16));
+            unsigned char* const scratch = reinterpret_cast<unsigned char*>(part) + lane * 8;   // masked rows store here (part is idle now)
+            float tp[16], ep[16];   // previous fragment: accumulators / SiLU intermediates
+            int nfp = 0;
+            // vector instruction number `op` of the epilogue of the previous fragment (68 in all)
+            auto epi_op = [&](int op) {
+                if (op < 16) ep[op] = __builtin_amdgcn_exp2f(-tp[op]);
+                else if (op < 32) ep[op - 16] = 1.0f + ep[op - 16];
+                else if (op < 48) ep[op - 32] = __builtin_amdgcn_rcpf(ep[op - 32]);
+                else if (op < 64) tp[op - 48] = tp[op - 48] * ep[op - 48];
+                else if (op < 68) {
+                    const int pf = op - 64;
+                    h4 o;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
+                    for (int j = 0; j < 4; ++j) o[j] = (_Float16)tp[4 * pf + j];
+                    unsigned char* dst = ED + (16 * pf + m) * T7_ES + (16 * nfp + 4 * q) * 2;
+                    *reinterpret_cast<h4*>((16 * pf + m < T7_PIX) ? dst : scratch) = o;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {   // i = 9 only drains the last fragment's epilogue
                 const int ir = i + rot >= 9 ? i + rot - 9 : i + rot;
                 const int nf = 9 * wave + ir;
                 h8 wc[6];
-#pragma unroll
-                for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
-                const f4 bv = bvn;
-                if (i + 1 < 9) {
-                    const int nfn = 9 * wave + (ir + 1 >= 9 ? ir + 1 - 9 : ir + 1);
-                    bvn = gload<f4>(W.bexp, (unsigned)(16 * nfn + 4 * q) * 4u);
-#pragma unroll
-                    for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)(((nfn * 6 + ks) * 64 + lane) * 16));
-                }
                 f4 acc[4];
+                if (i < 9) {
 #pragma unroll
-                for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
-                long long st0 = 0, st1 = 0, st2 = 0;   // diagnostic stamps of fragment 4 (clock build only)
-                if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st0 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+                    for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
+                    const f4 bv = bvn;
+                    if (i + 1 < 9) {
+                        const int nfn = 9 * wave + (ir + 1 >= 9 ? ir + 1 - 9 : ir + 1);
+                        bvn = gload<f4>(W.bexp, (unsigned)(16 * nfn + 4 * q) * 4u);
 #pragma unroll
-                for (int ks = 0; ks < 6; ++ks)
+                        for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)(((nfn * 6 + ks) * 64 + lane) * 16));
+                    }
+                    PIN_VMEM();
 #pragma unroll
-                    for (int pf = 0; pf < 4; ++pf)
-                        acc[pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xb[pf][ks], acc[pf], 0, 0, 0);
-                if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st1 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-                {
-                    float t[16];
+                    for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
+                }
 #pragma unroll
-                    for (int pf = 0; pf < 4; ++pf)
+                for (int slot = 0; slot < 24; ++slot) {
+                    if (i < 9) acc[slot & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[slot >> 2], xb[slot & 3][slot >> 2], acc[slot & 3], 0, 0, 0);
+                    if (i > 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) t[4 * pf + j] = acc[pf][j];
-                    silu_scaled_staged(t);
-                    if (i == 4 && clk_on && nb == 1) { __builtin_amdgcn_sched_barrier(0); st2 = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) {
-                        if (16 * pf + m < T7_PIX) {
-                            h4 o;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) o[j] = (_Float16)t[4 * pf + j];
-                            *reinterpret_cast<h4*>(ED + (16 * pf + m) * T7_ES + (16 * nf + 4 * q) * 2) = o;
-                        }
+                        for (int v = 0; v < 3; ++v)
+                            if (3 * slot + v < 68) epi_op(3 * slot + v);
+                    }
+                    if (i > 0 && i < 9) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // ... then three vector instructions
                     }
                 }
-                if (i == 4 && clk_on && nb == 1 && lane == 0 && (wave == 0 || wave == 4)) {
-                    const long long st3 = (long long)__builtin_readcyclecounter();
-                    float* dst = a.dbg_clk + ((size_t)b * 8 + 7) * 8 + (wave ? 4 : 0);
-                    dst[0] = (float)(st1 - st0); dst[1] = (float)(st2 - st1); dst[2] = (float)(st3 - st2); dst[3] = (float)(st0 - tk[0]);
+                if (i < 9) {
+#pragma unroll
+                    for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tp[4 * pf + j] = acc[pf][j];
+                    nfp = nf;
                 }
             }
         }
@@ -2791,6 +2810,8 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
     const int ty = tile >> 1, tx = tile & 1;
     const int oy0 = 8 * ty, ox0 = 28 * tx, iy0 = 16 * ty, ix0 = 56 * tx;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * 112 * 112 * 32;
+    float kdw[9], dbias;
+    const int cg_dw = chunk * 32 + (tid & 31);
     // ---------------- expand (with block 0's gate + project in front) ----------------
     {
         u4v xr[8];
@@ -2824,6 +2845,11 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
             wexp[nf] = *reinterpret_cast<const h8*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));
             bexp[nf] = a.bexp[chunk * 32 + 16 * nf + m];
         }
+        // depthwise taps and bias of this thread's channel, behind the expand's operands and pinned (see mbt_kernel)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) kdw[i] = a.wdw[(size_t)i * 96 + cg_dw];
+        dbias = a.bdw[cg_dw];
+        PIN_VMEM();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
@@ -2833,13 +2859,20 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
             h8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) xb[j] = (_Float16)x1[j];   // block 0's output, rounded as the separate path stores it
+            float t[8];   // both output fragments' accumulators: SiLU staged over all eight
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
                 // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
                 const f4 bv = {bexp[nf], bexp[nf], bexp[nf], bexp[nf]};
                 const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb, wexp[nf], bv, 0, 0, 0);
-                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
-                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
+            }
+            silu_scaled_staged(t);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
+                const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
                 const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
                 unsigned char* dst = E + ppair[i] * ES2 + (16 * nf + m) * 4;
                 *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
@@ -2855,13 +2888,11 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
         uint32_t wq[3][2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const float k0 = a.wdw[(size_t)(ky * 3 + 0) * 96 + cg], k1 = a.wdw[(size_t)(ky * 3 + 1) * 96 + cg],
-                        k2 = a.wdw[(size_t)(ky * 3 + 2) * 96 + cg];
+            const float k0 = kdw[ky * 3 + 0], k1 = kdw[ky * 3 + 1], k2 = kdw[ky * 3 + 2];
             h2 w0 = {(_Float16)k0, (_Float16)k1}, w1 = {(_Float16)k2, (_Float16)0.0f};
             wq[ky][0] = *reinterpret_cast<uint32_t*>(&w0);
             wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
         }
-        const float dbias = a.bdw[cg];
         const unsigned char* col = E + 4 * c;
         uint32_t P[3][15];
 #pragma unroll
@@ -2883,11 +2914,11 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
                                                     acc[j], false);
         float psum = 0.f;
         _Float16* dg = a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg;
+        silu_scaled_staged(acc);
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
-            const float y = silu_scaled(acc[j]);
-            psum += y;
-            dg[(size_t)j * 96] = (_Float16)y;
+            psum += acc[j];
+            dg[(size_t)j * 96] = (_Float16)acc[j];
         }
         pred[(tid >> 5) * 32 + c] = psum;
     }
@@ -2931,6 +2962,9 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
     const int Cin = a.Cin;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HIMG * HIMG * Cin;
     const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    uint32_t raw[15];
+    float dbias;
+    const int cg_dw = chunk * CH + tid % CH;
     // ---------------- expand ----------------
     {
         u4v xr[4][CKS];
@@ -2964,6 +2998,12 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
             for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
             ba[nf] = a.bexp[16 * nfg + m];
         }
+        // depthwise taps and bias of this thread's channel: requested behind the expand's operands (in-order return: they
+        // delay nothing) and pinned here, so their round trip is hidden by the expand instead of opening the depthwise phase
+#pragma unroll
+        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg_dw];
+        dbias = a.bdw[cg_dw];
+        PIN_VMEM();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
@@ -2975,14 +3015,21 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                 xb[ks] = *reinterpret_cast<const h8*>(&mk);
             }
             const int pair0 = 8 * (wave + 8 * i) + 2 * q;
+            float t[12];   // the three output fragments' accumulators: SiLU staged over all twelve
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) {
                 // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
                 f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
 #pragma unroll
                 for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
-                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
-                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
+            }
+            silu_scaled_staged(t);
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
+                const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
                 const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
                 unsigned char* dst = E + pair0 * ES2 + (16 * nf + m) * 4;
                 *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
@@ -2998,10 +3045,6 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
         const int band = rest % 5, half = rest / 5;
         const int rb = 3 * band;
         const int cg = chunk * CH + c;
-        uint32_t raw[15];
-#pragma unroll
-        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg];
-        const float dbias = a.bdw[cg];
         // window pair columns of this half: local pair l (0..8) <-> window pair (cbase/2 - 1 + l); cbase is even
         const int cbase = ox0 + 14 * half - wx0;
         const int pb = (cbase >> 1) - 1;
@@ -3048,11 +3091,11 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                                                             *reinterpret_cast<const h2*>(&wq[j & 1][ip]), acc[j], false);
                         }
                 }
+                silu_scaled_staged(acc);
 #pragma unroll
                 for (int j = 0; j < 14; ++j) {
-                    const float y = silu_scaled(acc[j]);
-                    psum += y;
-                    if (dw_thr) dg[((size_t)ro * HIMG + j) * CE] = (_Float16)y;
+                    psum += acc[j];
+                    if (dw_thr) dg[((size_t)ro * HIMG + j) * CE] = (_Float16)acc[j];
                 }
             }
         }
@@ -3096,6 +3139,9 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
     const int Cin = a.Cin;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HIMG * HIMG * Cin;
     const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    uint32_t raw[15];
+    float dbias;
+    const int cg_dw = chunk * CH + tid % CH;
     // ---------------- expand ----------------
     {
         u4v xr[NS][CKS];
@@ -3129,6 +3175,11 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
             for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
             ba[nf] = a.bexp[16 * nfg + m];
         }
+        // depthwise taps and bias of this thread's channel, behind the expand's operands and pinned (see mbt_kernel)
+#pragma unroll
+        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg_dw];
+        dbias = a.bdw[cg_dw];
+        PIN_VMEM();
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
@@ -3140,13 +3191,20 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
                 xb[ks] = *reinterpret_cast<const h8*>(&mk);
             }
             const int pair0 = 8 * (wave + 8 * i) + 2 * q;
+            float t[12];   // the three output fragments' accumulators: SiLU staged over all twelve
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) {
                 f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
 #pragma unroll
                 for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
-                h2 p0 = {(_Float16)silu_scaled(acc[0]), (_Float16)silu_scaled(acc[1])};
-                h2 p1 = {(_Float16)silu_scaled(acc[2]), (_Float16)silu_scaled(acc[3])};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
+            }
+            silu_scaled_staged(t);
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
+                const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
                 const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
                 unsigned char* dst = E + pair0 * ES2 + (16 * nf + m) * 4;
                 *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
@@ -3161,10 +3219,6 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
         const bool dw_thr = orow < 7;
         const int orc = dw_thr ? orow : 0;
         const int cg = chunk * CH + c;
-        uint32_t raw[15];
-#pragma unroll
-        for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg];
-        const float dbias = a.bdw[cg];
         const unsigned char* col = E + 4 * c;
         uint32_t P[KSD][NPR];
 #pragma unroll
@@ -3195,11 +3249,11 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
         }
         float psum = 0.f;
         _Float16* dg = a.D + (((size_t)b * HOUT + oy0 + orc) * HOUT + ox0) * CE + cg;
+        silu_scaled_staged(acc);
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
-            const float y = silu_scaled(acc[j]);
-            psum += y;
-            if (dw_thr) dg[(size_t)j * CE] = (_Float16)y;
+            psum += acc[j];
+            if (dw_thr) dg[(size_t)j * CE] = (_Float16)acc[j];
         }
         if (dw_thr) pred[orow * CH + c] = psum;
     }

@@ -32,8 +32,6 @@ def main():
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
     for s in range(1, 5):
         print(f"b{11 + s} : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(names, med[s][:6])) + f"   total {med[s][:6].sum():8.0f}")
-    print("b13 expand, fragment 4 of wave 0 / wave 4: " + " | ".join(
-        f"mfma {med[7][o]:5.0f} silu {med[7][o + 1]:5.0f} store {med[7][o + 2]:5.0f} (starts at {med[7][o + 3]:6.0f})" for o in (0, 4)))
     print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
 
 if __name__ == "__main__":
