@@ -2604,6 +2604,9 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     const int rb = 3 * band;
 #pragma unroll 1
     for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
+        long long ck[5] = {0, 0, 0, 0, 0};
+        const bool clk = a.dbg_clk && chunk == (int)blockIdx.y;
+        if (clk) ck[0] = (long long)__builtin_readcyclecounter();
         // taps and bias of this thread's channel: requested now, used after the expand phase
         uint32_t raw[15];
         const int cg = chunk * CH + (dw_thr ? cd : 0);
@@ -2683,7 +2686,9 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
             if (npf == 2) expand_chunk(std::integral_constant<int, 2>{});
             else expand_chunk(std::integral_constant<int, 1>{});
         }
+        if (clk) ck[1] = (long long)__builtin_readcyclecounter();
         T7_BAR();
+        if (clk) ck[2] = (long long)__builtin_readcyclecounter();
         // ---------------- depthwise ----------------
         float psum = 0.f;
         {
@@ -2774,7 +2779,15 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
             }
             if (dw_thr) pband[band * CH + cd] = psum;
         }
+        if (clk) ck[3] = (long long)__builtin_readcyclecounter();
         T7_BAR();
+        if (clk && lane == 0) {   // per wave: expand, wait at barrier 1, depthwise, wait at barrier 2 (waves 0, 4 and 7 recorded)
+            ck[4] = (long long)__builtin_readcyclecounter();
+            if (wave == 0 || wave == 4 || wave == 7) {
+                float* dst = a.dbg_clk + ((size_t)b * 8 + blockIdx.y) * 16 + (wave == 0 ? 0 : (wave == 4 ? 4 : 8));
+                for (int i = 0; i < 4; ++i) dst[i] = (float)(ck[i + 1] - ck[i]);
+            }
+        }
         if (tid < CH)
             a.pool[(size_t)b * CE + chunk * CH + tid] =
                 ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid] + (NBAND == 5 ? pband[4 * CH + tid] : 0.f);
@@ -3362,11 +3375,11 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
                 // Columns beyond K (zero-padded k-steps) re-read the row's last 8 channels: their gate and weights are
                 // zero, so no lane predicate is needed -- a per-lane branch around the load would make the compiler
                 // drain ALL outstanding loads (vmcnt(0)) at every chunk boundary and undo the prefetch.
+                // (No masking either: the re-read values are finite depthwise outputs and meet a zero gate, so they contribute an
+                // exact zero.  The select that used to zero them consumed each load at once -- at the register limit the compiler
+                // then issued the loads one at a time, each behind an s_waitcnt vmcnt(0): 14 exposed round trips in the prologue.)
                 const int k = 32 * (ch * CK + u) + 8 * q;
-                const u4v raw = gload<u4v>(xg, (unsigned)((pix * K + (k < K ? k : K - 8)) * 2));
-                const uint32_t keep = k < K ? 0xffffffffu : 0u;   // select, not a branch
-                const u4v msk = {raw.x & keep, raw.y & keep, raw.z & keep, raw.w & keep};
-                dst[i][u] = *reinterpret_cast<const h8*>(&msk);
+                dst[i][u] = gload<h8>(xg, (unsigned)((pix * K + (k < K ? k : K - 8)) * 2));
             }
         }
     };
@@ -3374,16 +3387,12 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     if (tid + 512 < KP) pooled[tid + 512] = tid + 512 < K ? ps1 : 0.f;
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 3] = (float)((long long)__builtin_readcyclecounter() - tk0);
-    // bulk loads: first pixel fragments of this wave, project weights (registers now, parked in LDS after FC2)
-    h8 xc[2][CK], xn[2][CK];
-    if (wave < NPAIR) load_chunk(wave, 0, xc);
-    h8 wreg[WPT];
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int c = tid + 512 * i;
-        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
-    }
     // ---- FC1: r = silu(br + psc * pooled . Wr^T) ----
+    // (The bulk loads -- 147 KB of project weights and the first pixel fragments, 33 x 16 bytes per thread -- used to be issued
+    // HERE, in front of FC1: their address processing alone takes ~4 k cycles per workgroup and FC1's barrier came 9-10 k cycles
+    // after the pooled one.  They are needed only after FC2, so they now go out behind FC1 and stream in under the reduce and FC2.)
+    h8 xc[2][CK], xn[2][CK];
+    h8 wreg[WPT];
     if (fc1_thr) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -3399,6 +3408,14 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     }
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
+    // bulk loads: project weights (registers now, parked in LDS after FC2), first pixel fragments of this wave
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int c = tid + 512 * i;
+        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
+    }
+    if (wave < NPAIR) load_chunk(wave, 0, xc);
+    PIN_VMEM();
     if (tid < CSP) {
         float s = 0.f;
 #pragma unroll 8

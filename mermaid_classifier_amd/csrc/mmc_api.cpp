@@ -245,6 +245,7 @@ struct mmc_backbone {
     std::vector<void*> allocs;
     bool keep = false, fuse_stem = false;
     float* dbg_clk = nullptr;        // keep mode: per-patch phase cycle counts of the patch-resident kernels
+    float* mid_clk = nullptr;        // MMC_TAIL_CLK=1: [max_batch][8 workgroups][16] phase cycle counts of block 10's mid14 launch
     float* tail_clk = nullptr;       // MMC_TAIL_CLK=1: [max_batch][8 sections][8] phase cycle counts of the production tail7 launch
     // tail7 extensions: block 11's squeeze-excite + project (pre-block) and the head conv inside the same launch
     // block 0's SE scale + project conv folded into block 1's fused kernel (mbconv_a_kernel PRE): no b0 output tensor
@@ -429,6 +430,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
       if (e && e[0] == '1' && !bb->keep) {
           int r__ = dev_alloc(bb, &bb->tail_clk, (size_t)max_batch * 64); if (r__) { mmc_backbone_destroy(bb); return r__; }
           hipMemset(bb->tail_clk, 0, (size_t)max_batch * 64 * sizeof(float));
+          r__ = dev_alloc(bb, &bb->mid_clk, (size_t)max_batch * 128); if (r__) { mmc_backbone_destroy(bb); return r__; }
+          hipMemset(bb->mid_clk, 0, (size_t)max_batch * 128 * sizeof(float));
           bb->use_graph = false;
       } }
     std::vector<uint64_t> table(2 * (size_t)nt);
@@ -988,6 +991,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
             { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (B.d.s == 2 ? 7 : 4); }
             ma.stride = B.d.s;
+            if (bb->mid_clk && i == 10) ma.dbg_clk = bb->mid_clk + (size_t)(&ws - bb->lanes) * bb->lane_cap * 128;
             nparts = 1;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char ml[48];
@@ -1277,6 +1281,15 @@ extern "C" int mmc_backbone_read_activation(mmc_backbone* bb, const char* name, 
                                             size_t* n_written)
 {
     if (!bb || !name || !out) return fail(MMC_ERR_ARG, "NULL argument");
+    if (bb->mid_clk && strcmp(name, "mid14.clk") == 0) {
+        const size_t ne = (size_t)bb->max_batch * 128;
+        if (ne > capacity) return fail(MMC_ERR_ARG, "'mid14.clk' has %zu elements, capacity %zu", ne, capacity);
+        HIP_TRY(hipSetDevice(bb->device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, bb->mid_clk, ne * 4, hipMemcpyDeviceToHost));
+        if (n_written) *n_written = ne;
+        return MMC_OK;
+    }
     if (bb->tail_clk && strcmp(name, "tail.clk") == 0) {   // MMC_TAIL_CLK=1: phase clock of the last production pass
         const size_t ne = (size_t)bb->max_batch * 64;
         if (ne > capacity) return fail(MMC_ERR_ARG, "'tail.clk' has %zu elements, capacity %zu", ne, capacity);

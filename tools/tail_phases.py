@@ -32,6 +32,11 @@ def main():
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
     for s in range(1, 5):
         print(f"b{11 + s} : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(names, med[s][:6])) + f"   total {med[s][:6].sum():8.0f}")
+    mc = bb.read_activation("mid14.clk", n * 128).reshape(n, 8, 16)[:, :4, :]       # 4 workgroups per patch
+    mm = np.median(mc.reshape(-1, 16), axis=0)
+    print("mid14 (block 10, first chunk of each workgroup), per wave: expand | wait at barrier | depthwise | wait at barrier")
+    for nm, o in (("wave 0", 0), ("wave 4", 4), ("wave 7", 8)):
+        print(f"  {nm}: {mm[o]:7.0f} | {mm[o + 1]:7.0f} | {mm[o + 2]:7.0f} | {mm[o + 3]:7.0f}")
     print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
 
 if __name__ == "__main__":
