@@ -2809,7 +2809,7 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 //            two v_dot2c per kernel row and output ((k0,k1) on pair j, (k2,0) on pair j+1), silu, fp16 to HBM,
 //            pool sums through LDS -> pool[patch][tile][96].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
+__global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: two workgroups per CU (one: 105 vs 94 us)
 {
     // The window is enumerated with 58 columns (29 pixel pairs; the 58th column is one more real pixel, or zero past the image):
     // a 4-position group of the un-swapped expand MFMA is two whole pairs, stored as E2[17 x 29 pairs][32 channels] dwords.
@@ -2819,17 +2819,17 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
     float* pred = reinterpret_cast<float*>(smem + NPF * 8 * ES2);    // [16][32] pool partials
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int tile = blockIdx.x, b = blockIdx.z;
     const int ty = tile >> 1, tx = tile & 1;
     const int oy0 = 8 * ty, ox0 = 28 * tx, iy0 = 16 * ty, ix0 = 56 * tx;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * 112 * 112 * 32;
-    float kdw[9], dbias;
-    const int cg_dw = chunk * 32 + (tid & 31);
-    // ---------------- expand (with block 0's gate + project in front) ----------------
+    // ---------------- block 0's gate + project, ONCE per tile: the projected fragments (4 fp16 per lane and fragment) stay in
+    // registers and feed the expand of all three 32-channel chunks.  (One workgroup per (tile, chunk) read block 0's depthwise output
+    // three times -- 320 MB fetched per 128 patches against 103 MB -- and redid the gate + project MFMA per chunk.) ----------------
+    bool okp[8][2];   // validity of this lane's two OUTPUT pairs (positions 16 pf + 4q .. +3): inside the window and the image
+    uint2 xbp[8];     // block 0's output fragment (k = 4q .. 4q+3 of 16), rounded as the separate path stores it
     {
         u4v xr[8];
-        bool okp[8][2];   // validity of this lane's two OUTPUT pairs (positions 16 pf + 4q .. +3): inside the window and the image
-        int ppair[8];     // index of the first of them
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pf = wave + 8 * i;
@@ -2839,7 +2839,6 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
             const bool ok = pf < NPF && p < NPOS && iy < 112 && ix < 112;
             xr[i] = gload<u4v>(xg, (unsigned)((((ok ? iy : 0) * 112 + (ok ? ix : 0)) * 32 + 8 * q) * 2));
             const int p0 = 16 * pf + 4 * q;
-            ppair[i] = p0 >> 1;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int pp = p0 + 2 * h;                 // even position: the pair (pp, pp+1) lies in one row
@@ -2851,27 +2850,49 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
         const f4 bpre = *reinterpret_cast<const f4*>(a.pre_b + 4 * q);
         const f4 g0 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q);
         const f4 g1 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q + 4);
-        h8 wexp[2];
-        float bexp[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 xin = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+            const uint4 gx = gate_h8(xin, g0, g1);
+            const f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&gx), bpre, 0, 0, 0);
+            h4 xh;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xh[j] = (_Float16)x1[j];
+            xbp[i] = *reinterpret_cast<const uint2*>(&xh);
+        }
+    }
+    // operands of a chunk: two expand weight fragments + biases, this thread's nine depthwise taps + bias; the next chunk's are
+    // requested in front of the current chunk's depthwise phase
+    h8 wexp[2];
+    float bexp[2];
+    float kdw[9], dbias;
+    auto request_chunk = [&](int chunk) {
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
             wexp[nf] = *reinterpret_cast<const h8*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));
             bexp[nf] = a.bexp[chunk * 32 + 16 * nf + m];
         }
-        // depthwise taps and bias of this thread's channel, behind the expand's operands and pinned (see mbt_kernel)
+    };
+    auto request_taps = [&](int chunk) {
+        const int cg_dw = chunk * 32 + (tid & 31);
 #pragma unroll
         for (int i = 0; i < 9; ++i) kdw[i] = a.wdw[(size_t)i * 96 + cg_dw];
         dbias = a.bdw[cg_dw];
-        PIN_VMEM();
+    };
+    request_chunk(0);
+    request_taps(0);
+#pragma unroll 1
+    for (int chunk = 0; chunk < 3; ++chunk) {
+        // ---------------- expand ----------------
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
-            const uint4 xin = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-            const uint4 gx = gate_h8(xin, g0, g1);
-            const f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&gx), bpre, 0, 0, 0);
             h8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
+            {
+                const h4 xh = *reinterpret_cast<const h4*>(&xbp[i]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xb[j] = (_Float16)x1[j];   // block 0's output, rounded as the separate path stores it
+                for (int j = 0; j < 4; ++j) xb[j] = xh[j];
+            }
             float t[8];   // both output fragments' accumulators: SiLU staged over all eight
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
@@ -2887,60 +2908,63 @@ __global__ __launch_bounds__(512) void mb1_kernel(Mb1Args a)
                 const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
                 const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
                 const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
-                unsigned char* dst = E + ppair[i] * ES2 + (16 * nf + m) * 4;
+                unsigned char* dst = E + (8 * (wave + 8 * i) + 2 * q) * ES2 + (16 * nf + m) * 4;   // first output pair: (16 pf + 4 q) / 2
                 *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
                 *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
             }
         }
-    }
-    T7_BAR();
-    // ---------------- depthwise 3x3 stride 2 ----------------
-    {
-        const int c = tid & 31, orow = (tid >> 5) & 7, half = tid >> 8;
-        const int cg = chunk * 32 + c;
-        uint32_t wq[3][2];
+        if (chunk + 1 < 3) request_chunk(chunk + 1);   // lands during the depthwise phase
+        T7_BAR();
+        // ---------------- depthwise 3x3 stride 2 ----------------
+        {
+            const int c = tid & 31, orow = (tid >> 5) & 7, half = tid >> 8;
+            const int cg = chunk * 32 + c;
+            uint32_t wq[3][2];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const float k0 = kdw[ky * 3 + 0], k1 = kdw[ky * 3 + 1], k2 = kdw[ky * 3 + 2];
-            h2 w0 = {(_Float16)k0, (_Float16)k1}, w1 = {(_Float16)k2, (_Float16)0.0f};
-            wq[ky][0] = *reinterpret_cast<uint32_t*>(&w0);
-            wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
+            for (int ky = 0; ky < 3; ++ky) {
+                const float k0 = kdw[ky * 3 + 0], k1 = kdw[ky * 3 + 1], k2 = kdw[ky * 3 + 2];
+                h2 w0 = {(_Float16)k0, (_Float16)k1}, w1 = {(_Float16)k2, (_Float16)0.0f};
+                wq[ky][0] = *reinterpret_cast<uint32_t*>(&w0);
+                wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
+            }
+            const float dbias_c = dbias;
+            if (chunk + 1 < 3) request_taps(chunk + 1);
+            const unsigned char* col = E + 4 * c;
+            uint32_t P[3][15];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const unsigned char* rowp = col + ((2 * orow + ky) * 29 + 14 * half) * ES2;
+#pragma unroll
+                for (int pp = 0; pp < 15; ++pp) P[ky][pp] = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
+            }
+            float acc[14];
+#pragma unroll
+            for (int j = 0; j < 14; ++j) acc[j] = dbias_c;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int j = 0; j < 14; ++j)
+                        acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
+                                                        acc[j], false);
+            float psum = 0.f;
+            _Float16* dg = a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg;
+            silu_scaled_staged(acc);
+#pragma unroll
+            for (int j = 0; j < 14; ++j) {
+                psum += acc[j];
+                dg[(size_t)j * 96] = (_Float16)acc[j];
+            }
+            pred[(tid >> 5) * 32 + c] = psum;
         }
-        const unsigned char* col = E + 4 * c;
-        uint32_t P[3][15];
+        T7_BAR();   // E and pred are free again behind this barrier (the pool sums below only read pred, rewritten two barriers on)
+        if (tid < 32) {
+            float s = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const unsigned char* rowp = col + ((2 * orow + ky) * 29 + 14 * half) * ES2;
-#pragma unroll
-            for (int pp = 0; pp < 15; ++pp) P[ky][pp] = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
+            for (int w = 0; w < 16; ++w) s += pred[w * 32 + tid];
+            a.pool[((size_t)b * 14 + tile) * 96 + chunk * 32 + tid] = s;
         }
-        float acc[14];
-#pragma unroll
-        for (int j = 0; j < 14; ++j) acc[j] = dbias;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-                for (int j = 0; j < 14; ++j)
-                    acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
-                                                    acc[j], false);
-        float psum = 0.f;
-        _Float16* dg = a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg;
-        silu_scaled_staged(acc);
-#pragma unroll
-        for (int j = 0; j < 14; ++j) {
-            psum += acc[j];
-            dg[(size_t)j * 96] = (_Float16)acc[j];
-        }
-        pred[(tid >> 5) * 32 + c] = psum;
-    }
-    T7_BAR();
-    if (tid < 32) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) s += pred[w * 32 + tid];
-        a.pool[((size_t)b * 14 + tile) * 96 + chunk * 32 + tid] = s;
     }
 }
 
@@ -4230,7 +4254,7 @@ int launch_mb1(const Mb1Args& a, hipStream_t st)
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(mb1_kernel, dim3(14, 3, a.B), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(mb1_kernel, dim3(14, 1, a.B), dim3(512), lds, st, a);   // one workgroup per (tile, patch): walks the three channel chunks
     LAUNCH_CHECK();
     return 0;
 }
