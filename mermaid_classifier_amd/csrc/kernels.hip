@@ -3699,12 +3699,16 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
                 a = cv.v;
             }
             h8 o;
+            float tv[8];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], a, bsv[t], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[t * 4 + j] = (_Float16)silu_scaled(acc[j]);
+                for (int j = 0; j < 4; ++j) tv[t * 4 + j] = acc[j];
             }
+            silu_scaled_staged(tv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (_Float16)tv[j];
             if (ok) *reinterpret_cast<h8*>(E + p * SD_ES + q * 16) = o;   // lane (m,q): channels 8q..8q+7
         }
     }
@@ -3766,11 +3770,11 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         h8 o;
+        silu_scaled_staged(acc[t]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float y = silu_scaled(acc[t][j]);
-            pooled[j] += y;
-            o[j] = (_Float16)y;
+            pooled[j] += acc[t][j];
+            o[j] = (_Float16)acc[t][j];
         }
         *reinterpret_cast<h8*>(outb + ((size_t)oy * 112 + ox + t) * 32) = o;
     }
@@ -3780,8 +3784,15 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     for (int j = 0; j < 8; ++j) red[s * 32 + cg * 8 + j] = pooled[j];
     __syncthreads();
     if (tid < 32) {
-        float sum = 0.f;
-        for (int ss = 0; ss < 64; ++ss) sum += red[ss * 32 + tid];
+        float sum = 0.f;   // 16 partials requested at a time (one LDS latency per 16, not per partial), summed in the fixed order
+#pragma unroll
+        for (int s0 = 0; s0 < 64; s0 += 16) {
+            float pv[16];
+#pragma unroll
+            for (int ss = 0; ss < 16; ++ss) pv[ss] = red[(s0 + ss) * 32 + tid];
+#pragma unroll
+            for (int ss = 0; ss < 16; ++ss) sum += pv[ss];
+        }
         pool_part[((size_t)b * 49 + ty * 7 + tx) * 32 + tid] = sum;
     }
 }
