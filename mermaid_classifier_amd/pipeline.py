@@ -47,6 +47,9 @@ class BatchedExtractor:
         self._free = [torch.cuda.Event(), torch.cuda.Event()]
         self._done = [torch.cuda.Event(), torch.cuda.Event()]
         self._host = [torch.empty((self.cap, backbone.feature_dim), dtype=torch.float32).pin_memory() for _ in range(2)]
+        # one device feature buffer per slot: a pass sees the same (patches, features) pair every time its slot comes round, so the
+        # library's HIP-graph cache keeps hitting (a fresh output tensor per flush would mint a new combination per pass)
+        self._fdev = [torch.empty((self.cap, backbone.feature_dim), dtype=torch.float32, device=self.dev) for _ in range(2)]
         self._copy_stream = torch.cuda.Stream(device=self.dev)
         self._buf = self._bufs[0]
 
@@ -82,7 +85,7 @@ class BatchedExtractor:
             if fill == 0:
                 return
             compute.wait_stream(self._copy_stream)              # the cuts of this buffer have landed
-            feats_dev = self.bb.extract(self._bufs[cur][:fill])  # asynchronous on the compute stream
+            feats_dev = self.bb.extract(self._bufs[cur][:fill], out=self._fdev[cur][:fill])  # asynchronous on the compute stream
             self._free[cur].record(compute)
             self._host[cur][:fill].copy_(feats_dev, non_blocking=True)   # pinned: the D2H is stream-ordered too
             self._done[cur].record(compute)

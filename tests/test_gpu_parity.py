@@ -419,3 +419,51 @@ def test_graph_replay_is_bitwise_identical_to_plain_launches(checkpoint_path, mo
     for r in runs:
         assert np.array_equal(r, plain)
     assert np.array_equal(fresh, plain)
+
+
+def test_graph_cache_eviction_and_stream_switches_keep_results(checkpoint_path):
+    """include/mmc.h: the 32 most recently used (patches, features, n) combinations keep their HIP graph, older ones are
+    evicted and fall back to plain launches until they repeat; a call on a different stream than the previous one first waits
+    for that call's work (shared workspace).  40 distinct input buffers, each seen three times (capture on the third), on two
+    alternating streams: every result equals the plain-launch result of the same patches."""
+    import torch
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    base = torch.from_numpy(ref.natural_patches(6, seed=5)).cuda()
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
+    try:
+        want = bb.extract(base).clone()
+        bufs = [base.roll(i % 6, 0).clone() for i in range(40)]
+        outs = [torch.empty((6, 1280), dtype=torch.float32, device="cuda") for _ in range(40)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for i, (p, o) in enumerate(zip(bufs, outs)):
+                with torch.cuda.stream(streams[(i + rep) & 1]):
+                    bb.extract(p, out=o)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, want.roll(i % 6, 0)), i
+    finally:
+        bb.close()
+
+
+def test_phase_clock_build_gives_the_same_features(checkpoint_path, monkeypatch):
+    """MMC_TAIL_CLK=1 (the in-kernel phase clocks behind profiles/r02_tail_phases.txt) must not change a bit of the result, and
+    the clock buffer is filled for every workgroup."""
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    p = ref.natural_patches(6, seed=9)
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=8)
+    plain = bb.extract(p)
+    bb.close()
+    monkeypatch.setenv("MMC_TAIL_CLK", "1")
+    bc = Backbone(str(checkpoint_path), device=0, max_batch=8)
+    try:
+        assert np.array_equal(bc.extract(p), plain)
+        clk = bc.read_activation("tail.clk", 8 * 64).reshape(8, 8, 8)     # rows: lane 0's patches, then lane 1's from row 4
+        ran = clk[:, 6, 0] > 1e4                                           # whole-kernel cycles
+        assert ran.sum() == 6
+        assert (clk[ran][:, 1:5, :6] > 0).all()                            # every phase of blocks 12..15
+    finally:
+        bc.close()
