@@ -821,6 +821,7 @@ __global__ __launch_bounds__(256) void se_small_kernel(const float* __restrict__
         const float* pp = pool_part + (size_t)b * nparts * C + tid;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int p = 0;
+#pragma unroll 4   // 16 partials in flight per round trip (block 0 has 49 tiles: twelve dependent round trips otherwise); same sums
         for (; p + 3 < nparts; p += 4) {
             s0 += pp[(size_t)p * C];
             s1 += pp[(size_t)(p + 1) * C];
@@ -2002,8 +2003,14 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         T7_BAR();
         if (tid < 28) {
             float s = 0.f;
-#pragma unroll 8
-            for (int w = 0; w < 48; ++w) s += part[w * 32 + tid];
+#pragma unroll
+            for (int w0 = 0; w0 < 48; w0 += 16) {
+                float pv[16];
+#pragma unroll
+                for (int w = 0; w < 16; ++w) pv[w] = part[(w0 + w) * 32 + tid];
+#pragma unroll
+                for (int w = 0; w < 16; ++w) s += pv[w];
+            }
             rs[tid] = silu_f(s * (float)(1.0 / (49.0 * 1.4426950408889634)) + brv);
         }
         T7_BAR();
@@ -3441,9 +3448,15 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     if (wave < NPAIR) load_chunk(wave, 0, xc);
     PIN_VMEM();
     if (tid < CSP) {
-        float s = 0.f;
-#pragma unroll 8
-        for (int w = 0; w < 64; ++w) s += part[w * 32 + tid];
+        float s = 0.f;   // 16 partials per round of LDS reads (one latency per 16, not per partial), summed in the fixed order
+#pragma unroll
+        for (int w0 = 0; w0 < 64; w0 += 16) {
+            float pv[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) pv[w] = part[(w0 + w) * 32 + tid];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += pv[w];
+        }
         rs[tid] = silu_f(s * a.psc + brv);
     }
     T7_BAR();
