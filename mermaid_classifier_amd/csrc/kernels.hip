@@ -2611,9 +2611,6 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     const int rb = 3 * band;
 #pragma unroll 1
     for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
-        long long ck[5] = {0, 0, 0, 0, 0};
-        const bool clk = a.dbg_clk && chunk == (int)blockIdx.y;
-        if (clk) ck[0] = (long long)__builtin_readcyclecounter();
         // taps and bias of this thread's channel: requested now, used after the expand phase
         uint32_t raw[15];
         const int cg = chunk * CH + (dw_thr ? cd : 0);
@@ -2693,9 +2690,7 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
             if (npf == 2) expand_chunk(std::integral_constant<int, 2>{});
             else expand_chunk(std::integral_constant<int, 1>{});
         }
-        if (clk) ck[1] = (long long)__builtin_readcyclecounter();
         T7_BAR();
-        if (clk) ck[2] = (long long)__builtin_readcyclecounter();
         // ---------------- depthwise ----------------
         float psum = 0.f;
         {
@@ -2786,20 +2781,236 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
             }
             if (dw_thr) pband[band * CH + cd] = psum;
         }
-        if (clk) ck[3] = (long long)__builtin_readcyclecounter();
         T7_BAR();
-        if (clk && lane == 0) {   // per wave: expand, wait at barrier 1, depthwise, wait at barrier 2 (waves 0, 4 and 7 recorded)
-            ck[4] = (long long)__builtin_readcyclecounter();
-            if (wave == 0 || wave == 4 || wave == 7) {
-                float* dst = a.dbg_clk + ((size_t)b * 8 + blockIdx.y) * 16 + (wave == 0 ? 0 : (wave == 4 ? 4 : 8));
-                for (int i = 0; i < 4; ++i) dst[i] = (float)(ck[i + 1] - ck[i]);
-            }
-        }
         if (tid < CH)
             a.pool[(size_t)b * CE + chunk * CH + tid] =
                 ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid] + (NBAND == 5 ? pband[4 * CH + tid] : 0.f);
         // (the next chunk's expand writes E only after every wave passed the barrier above; pband is rewritten only
         // after the next chunk's first barrier)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// mid14m_kernel: the front half of a 14x14 MBConv block with the DEPTHWISE CONV ON THE MATRIX PIPE.
+//
+// Round 2's counters and phase clocks say the fused expand + depthwise kernels are bound by vector-instruction issue: per
+// output a 5x5 depthwise costs 15 v_dot2c (12.5 in theory) + 4 SiLU instructions + conversion / store / bookkeeping, the two
+// waves of a SIMD share one vector port, and the matrix pipe idles at 2-9 %.  A depthwise conv is a GEMM with a
+// block-diagonal weight matrix:  Y[c][p] = sum_t W[t][c] X[p + t][c]  =  sum_k A[c][k] B[k][p]  with k = (tap t, channel c'),
+// A[c][(t, c')] = W[t][c] * (c' == c),  B[(t, c')][p] = X[p + t][c'].  One v_mfma_f32_16x16x32_f16 takes a 16-channel group,
+// 16 pixels and TWO taps (k = 2 taps x 16 channels): 512 useful MACs of its 8192, i.e. 32 MAC/clk/SIMD -- the ideal rate of
+// v_dot2c (measured: 21.7) -- on a pipe that has nothing else to do, and the vector port is left with SiLU + pack + store
+// (~6 instructions per output instead of ~21).  The B operand is a plain 16-byte LDS read of pixel p + t, channels 8h .. 8h+7:
+// the expanded tensor is kept in [pixel slot][16 channels] rows on a zero-bordered 18 x 18 grid, so taps outside the image
+// read zeros and nothing is predicated.  The block-diagonal A fragments (one nonzero per lane row) are packed on the host
+// (`dwdiag`, 1 KB per channel group and tap pair: 13 for 5x5, 5 for 3x3).
+//
+// Work split: a WAVE owns whole 16-channel groups -- it expands its group for all 196 pixels (swapped MFMA: a lane gets 4
+// consecutive channels of one pixel) into its PRIVATE [326 slots][16] LDS region, runs the depthwise MFMAs over it, applies
+// SiLU, stores the depthwise output and reduces the pool sums in registers.  No data crosses waves after the block input has
+// been staged in LDS: ONE barrier per kernel, no lockstep, the two waves of a SIMD overlap one's MFMAs with the other's SiLUs.
+// Tap pairs: (ky, kx) with (ky + 1, kx) for ky = 0, 2 (and ky = 0 for 3x3) -- second tap 18 slots on; the last kernel row pairs
+// (kx, kx + 1) -- second tap one slot on; the odd tap is paired with a zero weight.  Two lane addresses (vertical / horizontal
+// pairs) + immediate offsets address every B fragment.
+// Output: D[B][196][CE], pool[B][CE] -- what mid14_kernel writes (sums in another, equally fixed, order).
+// ---------------------------------------------------------------------------------------------
+template <int CKS, int KSD, int CE>
+__global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
+{
+    constexpr int HW = 196, NG = CE / 16, R = KSD / 2, NT = (KSD * KSD + 1) / 2;
+    constexpr int XSTR = 64 * CKS + 32;          // bytes per staged block-input row (k zero padded to 32 CKS; +32: conflict-free ds_read_b128)
+    constexpr int ESLOTS = 18 * 18 + 2;          // zero-bordered 18 x 18 grid + two scratch slots for lanes past pixel 195
+    constexpr int EREG = ESLOTS * 32;            // bytes of a wave's private region: [slot][16 channels] fp16
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* XS = smem;                                   // [196][XSTR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* EW = smem + HW * XSTR + wave * EREG;         // this wave's region
+    const int p = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int Cin = a.Cin;
+    const long long ck0 = a.dbg_clk ? (long long)__builtin_readcyclecounter() : 0;
+    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.bexp);
+    const GLOBAL_AS _Float16* dwd = sgpr_ptr<_Float16>(a.dwdiag);
+    const GLOBAL_AS float* bdw = sgpr_ptr<float>(a.bdw);
+    // ---- stage the block input (k zero padded) and zero this wave's region (borders stay zero for the whole kernel) ----
+    {
+        const _Float16* xg = a.X + (size_t)b * HW * Cin;
+        constexpr int CPR = 4 * CKS;             // 16-byte chunks per staged row
+        for (int e = tid; e < HW * CPR; e += 512) {
+            const int row = e / CPR, c = e - row * CPR;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (8 * c < Cin) v = *reinterpret_cast<const uint4*>(xg + (size_t)row * Cin + 8 * c);
+            *reinterpret_cast<uint4*>(XS + row * XSTR + 16 * c) = v;
+        }
+        for (int e = lane; e < EREG / 16; e += 64) *reinterpret_cast<uint4*>(EW + 16 * e) = uint4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    long long ck[5] = {0, 0, 0, 0, 0};
+    const bool clk = a.dbg_clk != nullptr;
+    if (clk) ck[1] = (long long)__builtin_readcyclecounter();
+    // lane constants: B-operand addresses of the depthwise MFMAs for output row y are rowb + y * 18 * 32 + immediate
+    const int rowbV = p * 32 + 16 * (q & 1) + (q >> 1) * (18 * 32);   // vertical tap pairs: the second tap is one grid row down
+    const int rowbH = p * 32 + 16 * (q & 1) + (q >> 1) * 32;          // horizontal pairs: the second tap is one slot to the right
+    // operands of a channel group: expand weights (A, CKS fragments) + bias, block-diagonal depthwise fragments + bias.  The next
+    // group's are requested while the current group computes (17 KB per wave and group: an exposed L2 round trip otherwise).
+    h8 we[CKS], wd[NT], wen[CKS], wdn[NT];
+    f4 be, bd, ben, bdn;
+    auto request_group = [&](int g, h8 (&w1)[CKS], h8 (&w2)[NT], f4& b1, f4& b2) {
+#pragma unroll
+        for (int ks = 0; ks < CKS; ++ks) w1[ks] = gload<h8>(wexp, (unsigned)(((g * CKS + ks) * 64 + lane) * 16));
+        b1 = gload<f4>(bexp, (unsigned)(16 * g + 4 * q) * 4u);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w2[t] = gload<h8>(dwd, (unsigned)(((g * NT + t) * 64 + lane) * 16));
+        b2 = gload<f4>(bdw, (unsigned)(16 * g + 4 * q) * 4u);
+    };
+    {
+        const int g0 = blockIdx.y * 8 + wave;
+        request_group(g0 < NG ? g0 : 0, wen, wdn, ben, bdn);
+    }
+#pragma unroll 1
+    for (int g = blockIdx.y * 8 + wave; g < NG; g += 8 * gridDim.y) {
+#pragma unroll
+        for (int ks = 0; ks < CKS; ++ks) we[ks] = wen[ks];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wd[t] = wdn[t];
+        be = ben;
+        bd = bdn;
+        {
+            const int gn = g + 8 * (int)gridDim.y;
+            request_group(gn < NG ? gn : g, wen, wdn, ben, bdn);   // (the last group re-requests itself: unused)
+        }
+        PIN_VMEM();
+        // ---------------- expand: E[slot(pixel)][4q .. 4q+3] = silu(W_g . X[pixel] + b) for all 196 pixels ----------------
+        // Software pipeline inside the wave (it has ONE partner on its SIMD: nothing else hides its latencies): the B fragments
+        // of the next step are requested before the current step's MFMAs, and the MFMAs of step i are interleaved with the SiLU
+        // epilogue of step i - 1 (sched_group_barrier: one MFMA, then a few vector instructions).  Two pixel tiles per step.
+        auto x_frags = [&](int pt, h8 (&xb)[2][CKS]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pix = 16 * (pt + u) + p;
+                const unsigned char* xr = XS + (pix < HW ? pix : HW - 1) * XSTR + 16 * q;
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks) xb[u][ks] = *reinterpret_cast<const h8*>(xr + 64 * ks);
+            }
+        };
+        auto x_epilogue = [&](int pt, const f4 (&acc)[2]) {   // SiLU + store of tiles pt, pt + 1 (pt = 12: the 14th tile does not exist)
+            float t[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+            silu_scaled_staged(t);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pix = 16 * (pt + u) + p;
+                const int y = (pix * 4682) >> 16, x = pix - 14 * y;                   // pix / 14, pix % 14 (exact below 224)
+                const int slot = pix < HW ? (y + 2) * 18 + x + 2 : 324 + (p & 1);     // lanes past the last pixel: scratch slots
+                const h4 o = {(_Float16)t[4 * u], (_Float16)t[4 * u + 1], (_Float16)t[4 * u + 2], (_Float16)t[4 * u + 3]};
+                *reinterpret_cast<h4*>(EW + slot * 32 + 8 * q) = o;
+            }
+        };
+        {
+            h8 xa[2][CKS], xn[2][CKS];
+            f4 accp[2] = {be, be};
+            x_frags(0, xa);
+#pragma unroll
+            for (int st = 0; st < 7; ++st) {          // tiles 2 st, 2 st + 1 (the 14th is a repeat of the 13th, discarded by the scratch slots)
+                if (st + 1 < 7) x_frags(2 * (st + 1) < 12 ? 2 * (st + 1) : 12, xn);   // (step 6 = tiles 12, 13: both clamp to the last pixels)
+                f4 acc[2] = {be, be};
+#pragma unroll
+                for (int ks = 0; ks < CKS; ++ks)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(we[ks], xa[u][ks], acc[u], 0, 0, 0);
+                if (st > 0) x_epilogue(2 * (st - 1), accp);
+                if (st > 0) {
+#pragma unroll
+                    for (int i = 0; i < 2 * CKS; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) accp[u] = acc[u];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ks = 0; ks < CKS; ++ks) xa[u][ks] = xn[u][ks];
+            }
+            x_epilogue(12, accp);
+        }
+        if (clk && ck[2] == 0) ck[2] = (long long)__builtin_readcyclecounter();
+        // ---------------- depthwise on the matrix pipe, SiLU, store, pool sums: one output row per step, pipelined the same way
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        _Float16* dg = a.D + (size_t)b * HW * CE + 16 * g + 4 * q;
+        auto d_frags = [&](int y, h8 (&bf)[NT]) {
+            // output row y, columns p = 0 .. 15 (14, 15 are discarded): tap (ky, kx) reads slot (y + ky + 2 - R) * 18 + p + kx + 2 - R
+            const unsigned char* bv = EW + rowbV + ((y + 2 - R) * 18 + 2 - R) * 32;
+            const unsigned char* bh = EW + rowbH + ((y + 2 - R) * 18 + 2 - R) * 32;
+            int t = 0;
+#pragma unroll
+            for (int ky = 0; ky + 1 < KSD; ky += 2)
+#pragma unroll
+                for (int kx = 0; kx < KSD; ++kx, ++t) bf[t] = *reinterpret_cast<const h8*>(bv + (ky * 18 + kx) * 32);
+#pragma unroll
+            for (int kx = 0; kx < KSD; kx += 2, ++t) bf[t] = *reinterpret_cast<const h8*>(bh + ((KSD - 1) * 18 + kx) * 32);
+        };
+        auto d_epilogue = [&](int y, const f4& acc) {
+            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+            silu_scaled_staged(v);
+            const h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            const bool ok = p < 14;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps[j] += ok ? v[j] : 0.f;
+            if (ok) *reinterpret_cast<h4*>(dg + (size_t)(y * 14 + p) * CE) = o;
+        };
+        // a row's 13 (5) MFMAs run as TWO accumulation chains (even / odd tap pairs, added at the end): a single chain is paced
+        // by the dependent-accumulator latency, not by the pipe
+        auto d_row = [&](const h8 (&bf)[NT]) -> f4 {
+            f4 a0 = bd, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[t], bf[t], a1, 0, 0, 0);
+                else a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[t], bf[t], a0, 0, 0, 0);
+            }
+            return f4{a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
+        };
+        {
+            h8 ba[NT], bn[NT];
+            d_frags(0, ba);
+            d_frags(1, bn);
+            f4 accp = d_row(ba);                       // row 0 (peeled: nothing to overlap with yet)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) ba[t] = bn[t];
+#pragma unroll 1
+            for (int y = 1; y < 14; ++y) {
+                d_frags(y + 1 < 14 ? y + 1 : 13, bn);
+                const f4 acc = d_row(ba);
+                d_epilogue(y - 1, accp);               // the previous row's SiLU / store beside this row's MFMAs
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                accp = acc;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ba[t] = bn[t];
+            }
+            d_epilogue(13, accp);
+        }
+        // pool sums of the group's 16 channels: this lane holds 4 channels of pixel column p -> sum over the 16 columns
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = ps[j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8);
+            ps[j] = s;
+        }
+        if (p == 0) *reinterpret_cast<f4*>(a.pool + (size_t)b * CE + 16 * g + 4 * q) = f4{ps[0], ps[1], ps[2], ps[3]};
+        if (clk && ck[3] == 0) ck[3] = (long long)__builtin_readcyclecounter();
+    }
+    if (clk && lane == 0 && (wave == 0 || wave == 4 || wave == 7)) {   // staging | first group: expand | depthwise | all remaining groups
+        ck[4] = (long long)__builtin_readcyclecounter();
+        float* dst = a.dbg_clk + ((size_t)b * 8 + blockIdx.y) * 16 + (wave == 0 ? 0 : (wave == 4 ? 4 : 8));
+        dst[0] = (float)(ck[1] - ck0); dst[1] = (float)(ck[2] - ck[1]); dst[2] = (float)(ck[3] - ck[2]); dst[3] = (float)(ck[4] - ck[3]);
     }
 }
 
@@ -4254,10 +4465,33 @@ static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
     return 0;
 }
 
+template <int CKS, int KSD, int CE>
+static int launch_mid14m_t(const Mid14Args& a, hipStream_t st)
+{
+    const int lds = 196 * (64 * CKS + 32) + 8 * (18 * 18 + 2) * 32;   // staged block input + eight wave-private expanded regions
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14m_kernel<CKS, KSD, CE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    // two workgroups per patch: 16 waves share the CE / 16 channel groups (256 workgroups per 128-patch lane: one round)
+    hipLaunchKernelGGL((mid14m_kernel<CKS, KSD, CE>), dim3(a.B, a.nsplit < 1 ? 1 : a.nsplit), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_mid14(const Mid14Args& a, hipStream_t st)
 {
     if (a.B < 1) return -14;
     const int cks = (a.Cin + 31) / 32;
+    if (a.dwdiag && a.stride == 1) {   // depthwise on the matrix pipe (mid14m_kernel)
+        if (cks == 4 && a.ks == 5 && a.Ce == 672) return launch_mid14m_t<4, 5, 672>(a, st);   // b9, b10
+        if (cks == 3 && a.ks == 5 && a.Ce == 480) return launch_mid14m_t<3, 5, 480>(a, st);   // b8
+        if (cks == 3 && a.ks == 3 && a.Ce == 480) return launch_mid14m_t<3, 3, 480>(a, st);   // b6, b7
+        return -5;
+    }
     if (a.stride == 2) {
         if (cks == 4 && a.ks == 5 && a.Ce == 672) return launch_mid14_t<4, 5, 672, 2>(a, st);   // b11
         return -5;

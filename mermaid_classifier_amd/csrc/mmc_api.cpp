@@ -163,6 +163,7 @@ struct BlockW {
     // tail7_kernel packing (7x7 blocks 12..14): project weights in plain fragment order, depthwise tap pairs
     _Float16* t_wproj = nullptr;
     uint32_t* t_dwp = nullptr;
+    _Float16* dw_diag = nullptr;  // mid14m_kernel: block-diagonal depthwise fragments [ce/16][NT][64][8] (depthwise on the matrix pipe)
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
     // proj_patch_kernel packing (blocks 3..10): project weights/bias padded to whole fragments, SE FCs as above with
     // Cs padded to a multiple of 4
@@ -487,6 +488,9 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->mid14 = mid14_enabled;
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
+    // MMC_MID14M=1 (default 0): blocks 6..10 on mid14m_kernel -- depthwise conv as block-diagonal MFMAs, wave-private channel
+    // groups, one barrier per kernel; measured equal to mid14_kernel so far, kept as a tested variant
+    const bool mid14m_enabled = mid14_enabled && [] { const char* e = getenv("MMC_MID14M"); return e && e[0] == '1'; }();
     const char* mbt_env = getenv("MMC_MBT");
     const bool mbt_enabled = (fuse_enabled || fuse_generic_early) && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
@@ -545,6 +549,29 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             dp[(size_t)(ky * 3 + d) * B.ce + c] = u;
                         }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp, dp));
+            }
+            if (mid14m_enabled && i >= 6 && i <= 10 && H == 14 && B.d.s == 1 && B.ce % 16 == 0) {
+                // Depthwise on the matrix pipe (mid14m_kernel): Y[c][p] = sum_k A[c][k] B[k][p] with k = (tap, channel') and
+                // A[c][(t, c')] = W[t][c] (c' == c).  One MFMA fragment = a 16-channel group x two taps: lane (n = l & 15, qq = l >> 4)
+                // holds k = 8 qq .. 8 qq + 7 = tap (qq >> 1 ? second : first), channels 8 (qq & 1) .. +7 of the group -- one nonzero.
+                // Tap pairs in the kernel's order: rows (ky, ky + 1) for ky = 0, 2, ... column by column, then the last kernel row in
+                // horizontal pairs; an odd tap is paired with a zero.
+                const int K = B.d.k, NT = (K * K + 1) / 2, ngr = B.ce / 16;
+                std::vector<_Float16> dd((size_t)ngr * NT * 64 * 8, (_Float16)0.0f);
+                std::vector<int> ta, tb;   // tap indices ky * K + kx (-1: none)
+                for (int ky = 0; ky + 1 < K; ky += 2)
+                    for (int kx = 0; kx < K; ++kx) { ta.push_back(ky * K + kx); tb.push_back((ky + 1) * K + kx); }
+                for (int kx = 0; kx < K; kx += 2) { ta.push_back((K - 1) * K + kx); tb.push_back(kx + 1 < K ? (K - 1) * K + kx + 1 : -1); }
+                for (int g = 0; g < ngr; ++g)
+                    for (int t = 0; t < NT; ++t)
+                        for (int ln = 0; ln < 64; ++ln) {
+                            const int n = ln & 15, qq = ln >> 4;
+                            const int tapi = (qq >> 1) ? tb[t] : ta[t];
+                            const int j = n - 8 * (qq & 1);
+                            if (tapi < 0 || j < 0 || j >= 8) continue;
+                            dd[(((size_t)g * NT + t) * 64 + ln) * 8 + j] = (_Float16)(float)(w[(size_t)(16 * g + n) * kk + tapi] * tsc);
+                        }
+                TRY_OR_FREE(dev_upload(bb, &B.dw_diag, dd));
             }
         }
         {
@@ -989,13 +1016,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             Mid14Args ma{};
             ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
             ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
-            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (B.d.s == 2 ? 7 : 4); }
+            ma.dwdiag = (B.d.s == 1) ? B.dw_diag : nullptr;
+            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (ma.dwdiag ? 2 : (B.d.s == 2 ? 7 : 4)); }
             ma.stride = B.d.s;
             if (bb->mid_clk && i == 10) ma.dbg_clk = bb->mid_clk + (size_t)(&ws - bb->lanes) * bb->lane_cap * 128;
             nparts = 1;
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char ml[48];
-            snprintf(ml, sizeof ml, "mid14<%d,%d,%d,%d>", (B.d.cin + 31) / 32, B.d.k, B.ce, B.d.s);
+            snprintf(ml, sizeof ml, ma.dwdiag ? "mid14m<%d,%d,%d,%d>" : "mid14<%d,%d,%d,%d>", (B.d.cin + 31) / 32, B.d.k, B.ce, B.d.s);
             STEP(nm, ml, launch_mid14(ma, st));
         } else if (B.fused) {
             MbArgs a{};

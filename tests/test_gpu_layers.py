@@ -11,20 +11,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fused", "unfused"])
+@pytest.fixture(scope="module", params=["fused", "unfused", "fused-mfma-dw"])
 def kept_backbone(checkpoint_path, request):
     """fused: expand+depthwise in one kernel (the product schedule; the expanded tensor is never in
-    HBM, so there is no ``b<i>.expand`` tensor to compare).  unfused: MMC_FUSE=0, every tensor."""
+    HBM, so there is no ``b<i>.expand`` tensor to compare).  unfused: MMC_FUSE=0, every tensor.
+    fused-mfma-dw: MMC_MID14M=1, blocks 6..10 on mid14m_kernel (depthwise conv as block-diagonal MFMAs)."""
     os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
     if request.param == "unfused":
         os.environ["MMC_FUSE"] = "0"
+    if request.param == "fused-mfma-dw":
+        os.environ["MMC_MID14M"] = "1"
     try:
         from mermaid_classifier_amd.backbone import Backbone
         bb = Backbone(str(checkpoint_path), device=0, max_batch=4)
     finally:
         os.environ.pop("MMC_KEEP_ACTIVATIONS", None)
         os.environ.pop("MMC_FUSE", None)
-    bb.mode = request.param
+        os.environ.pop("MMC_MID14M", None)
+    bb.mode = "unfused" if request.param == "unfused" else "fused"
     yield bb
     bb.close()
 

@@ -32,9 +32,12 @@ def main():
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
     for s in range(1, 5):
         print(f"b{11 + s} : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(names, med[s][:6])) + f"   total {med[s][:6].sum():8.0f}")
-    mc = bb.read_activation("mid14.clk", n * 128).reshape(n, 8, 16)[:, :4, :]       # 4 workgroups per patch
+    if os.environ.get("MMC_MID14M") != "1":
+        print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
+        return
+    mc = bb.read_activation("mid14.clk", n * 128).reshape(n, 8, 16)[:, :2, :]       # 2 workgroups per patch (mid14m)
     mm = np.median(mc.reshape(-1, 16), axis=0)
-    print("mid14 (block 10, first chunk of each workgroup), per wave: expand | wait at barrier | depthwise | wait at barrier")
+    print("mid14m (block 10), per wave: staging + barrier | first group: expand | first group: depthwise | remaining groups")
     for nm, o in (("wave 0", 0), ("wave 4", 4), ("wave 7", 8)):
         print(f"  {nm}: {mm[o]:7.0f} | {mm[o + 1]:7.0f} | {mm[o + 2]:7.0f} | {mm[o + 3]:7.0f}")
     print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
