@@ -1141,7 +1141,8 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (i == 0 && bb->fuse_b0b1 && stem_fused) continue;   // block 0's project runs inside block 1's kernel
         snprintf(nm, sizeof nm, "b%d.project", i);
         const int pks = B.project.Kp / 32;
-        if (bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && pks <= 3 && B.project.N <= 32 &&   // (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
+        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 3; }();   // k-steps thin_proj takes (5-6: block 2's project, measured below)
+        if (bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && pks <= thin_max && B.project.N <= 32 &&   // (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
             (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136) {
             // small-K, small-N project on a big image (B4 blocks 0, 1; B0 block 1): stream one patch's fragments per workgroup
             GemmArgs a{};
