@@ -23,6 +23,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division: results are rounded to fp16 anyway.
 static __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -36,10 +37,28 @@ static __device__ __forceinline__ float silu_scaled(float t)
     return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
+// Two f32 -> one dword of two f16 (round to nearest even, gfx950's v_cvt_pk_f16_f32).  Written as asm because the compiler splits
+// an h2 whose halves are stored separately back into two single conversions.
+static __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b)
+{
+    uint32_t d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // Pins the loads written before it where they are written: nothing is scheduled across.  hipcc's scheduler otherwise sinks
 // a prefetch down to its first use, i.e. turns it into a plain load.  (A mask that lets ALU / MFMA / LDS instructions cross,
 // 0x78F, was measured far worse: tail7's project 12 k -> 23 k cycles, head 28 k -> 55 k -- the loads moved again.)
 #define PIN_VMEM() __builtin_amdgcn_sched_barrier(0)
+
+// First tap of a depthwise accumulator: d = dot2(a, b) + c with c in its own register (VOP3P v_dot2_f32_f16).  The builtin is
+// always selected as the two-address v_dot2c, which needs a v_mov per accumulator to start from the bias.
+static __device__ __forceinline__ float dot2_from(uint32_t a, uint32_t b, float c)
+{
+    float d;
+    asm("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 
 // The same on N accumulators at once, stage by stage (all exponentials, all adds, all reciprocals, all products): element by
 // element the four-instruction chain exp -> add -> rcp -> mul stalls on each transcendental's latency (the compiler pads it
@@ -47,15 +66,27 @@ static __device__ __forceinline__ float silu_scaled(float t)
 template <int N>
 static __device__ __forceinline__ void silu_scaled_staged(float (&t)[N])
 {
+    // the add and the product run two values per instruction (v_pk_add_f32 / v_pk_mul_f32: same IEEE results, half the issue
+    // slots); the transcendentals have no packed form
     float e[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_exp2f(-t[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) e[i] = 1.0f + e[i];
+    for (int i = 0; i + 1 < N; i += 2) {
+        f2 v = {e[i], e[i + 1]};
+        v = v + (f2){1.0f, 1.0f};
+        e[i] = v.x; e[i + 1] = v.y;
+    }
+    if (N & 1) e[N - 1] = 1.0f + e[N - 1];
 #pragma unroll
     for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = t[i] * e[i];
+    for (int i = 0; i + 1 < N; i += 2) {
+        f2 v = {t[i], t[i + 1]}, r = {e[i], e[i + 1]};
+        v = v * r;
+        t[i] = v.x; t[i + 1] = v.y;
+    }
+    if (N & 1) t[N - 1] = t[N - 1] * e[N - 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1846,10 +1877,8 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int kk = 32 * ks + 8 * q;
-                    const u4v rawx = gload<u4v>(xgp, (unsigned)((pixc * 112 + (kk < 112 ? kk : 104)) * 2));
-                    const uint32_t keep = kk < 112 ? 0xffffffffu : 0u;
-                    const u4v mk = {rawx.x & keep, rawx.y & keep, rawx.z & keep, rawx.w & keep};
-                    xb[i][ks] = *reinterpret_cast<const h8*>(&mk);
+                    // K columns 112..127 re-read channels 104..111: finite values against the zero rows the host packs there
+                    xb[i][ks] = gload<h8>(xgp, (unsigned)((pixc * 112 + (kk < 112 ? kk : 104)) * 2));
                 }
             }
             for (int e = tid; e < T7_PIX * 12; e += 512) {   // k-steps 21..23 of D11 are zeros
@@ -2629,10 +2658,8 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
                 const int kk = 32 * ks + 8 * q;
-                const u4v rawx = gload<u4v>(xg, (unsigned)((pixc * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
-                const uint32_t keep = kk < Cin ? 0xffffffffu : 0u;
-                const u4v mk = {rawx.x & keep, rawx.y & keep, rawx.z & keep, rawx.w & keep};
-                xb[i][ks] = *reinterpret_cast<const h8*>(&mk);
+                // zero-padded K columns re-read the last eight channels: finite values against the zero rows the host packs there
+                xb[i][ks] = gload<h8>(xg, (unsigned)((pixc * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
             }
         }
     }
@@ -3081,13 +3108,13 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
     }
     // operands of a chunk: two expand weight fragments + biases, this thread's nine depthwise taps + bias; the next chunk's are
     // requested in front of the current chunk's depthwise phase
-    h8 wexp[2];
+    h4 wexp[2];
     float bexp[2];
     float kdw[9], dbias;
     auto request_chunk = [&](int chunk) {
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
-            wexp[nf] = *reinterpret_cast<const h8*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));
+            wexp[nf] = *reinterpret_cast<const h4*>(a.wexp + ((size_t)(chunk * 32 + 16 * nf + m) * 32 + 8 * q));   // slots 8q .. 8q+3 = channels 4q .. 4q+3
             bexp[nf] = a.bexp[chunk * 32 + 16 * nf + m];
         }
     };
@@ -3102,21 +3129,20 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
 #pragma unroll 1
     for (int chunk = 0; chunk < 3; ++chunk) {
         // ---------------- expand ----------------
+        f4 bexp4[2];   // the bias as a ready accumulator operand, built once per chunk
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) bexp4[nf] = f4{bexp[nf], bexp[nf], bexp[nf], bexp[nf]};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
-            h8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
-            {
-                const h4 xh = *reinterpret_cast<const h4*>(&xbp[i]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xb[j] = xh[j];
-            }
+            // K = 16 MFMA: block 0's 16 output channels are exactly one k-step of it, and the projected fragment (k = 4q .. 4q+3 in
+            // lane quarter q) is its A operand as it stands -- no zero-padded upper half to assemble per fragment and chunk
+            const h4 xb = *reinterpret_cast<const h4*>(&xbp[i]);
             float t[8];   // both output fragments' accumulators: SiLU staged over all eight
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
                 // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
-                const f4 bv = {bexp[nf], bexp[nf], bexp[nf], bexp[nf]};
-                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb, wexp[nf], bv, 0, 0, 0);
+                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(xb, wexp[nf], bexp4[nf], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
             }
@@ -3157,24 +3183,27 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
             }
             float acc[14];
 #pragma unroll
-            for (int j = 0; j < 14; ++j) acc[j] = dbias_c;
-#pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-                    for (int j = 0; j < 14; ++j)
-                        acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
-                                                        acc[j], false);
-            float psum = 0.f;
-            _Float16* dg = a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg;
+                    for (int j = 0; j < 14; ++j) {
+                        if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ky][ip], dbias_c);
+                        else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
+                                                             acc[j], false);
+                    }
+            f2 psum2 = {0.f, 0.f};
+            uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg);
             silu_scaled_staged(acc);
 #pragma unroll
-            for (int j = 0; j < 14; ++j) {
-                psum += acc[j];
-                dg[(size_t)j * 96] = (_Float16)acc[j];
+            for (int j = 0; j < 14; j += 2) {
+                const f2 v = {acc[j], acc[j + 1]};
+                psum2 = psum2 + v;
+                const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);
+                dg[(size_t)j * 96] = (uint16_t)hv;
+                dg[(size_t)(j + 1) * 96] = (uint16_t)(hv >> 16);
             }
-            pred[(tid >> 5) * 32 + c] = psum;
+            pred[(tid >> 5) * 32 + c] = psum2.x + psum2.y;
         }
         T7_BAR();   // E and pred are free again behind this barrier (the pool sums below only read pred, rewritten two barriers on)
         if (tid < 32) {
@@ -3259,24 +3288,25 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
         for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg_dw];
         dbias = a.bdw[cg_dw];
         PIN_VMEM();
+        f4 ba4[3];   // the bias as a ready accumulator operand (built once: per fragment it was three v_mov per 16 channels)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) ba4[nf] = f4{ba[nf], ba[nf], ba[nf], ba[nf]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
             h8 xb[CKS];
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
-                const uint32_t keep = (32 * ks + 8 * q < Cin) ? 0xffffffffu : 0u;   // zero-padded K columns: select, not branch
-                const u4v mk = {xr[i][ks].x & keep, xr[i][ks].y & keep, xr[i][ks].z & keep, xr[i][ks].w & keep};
-                xb[ks] = *reinterpret_cast<const h8*>(&mk);
+                xb[ks] = *reinterpret_cast<const h8*>(&xr[i][ks]);   // (zero-padded K columns: finite re-reads x zero weight rows)
             }
             const int pair0 = 8 * (wave + 8 * i) + 2 * q;
             float t[12];   // the three output fragments' accumulators: SiLU staged over all twelve
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) {
                 // un-swapped: lane (m, q) = channel 16 nf + m of positions 16 pf + 4q .. +3 = two pixel pairs
-                f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
+                f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0], wa[nf][0], ba4[nf], 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
+                for (int ks = 1; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
             }
@@ -3295,36 +3325,37 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
     T7_BAR();
     // ---------------- depthwise ----------------
     {
-        const int c = tid % CH, rest = tid / CH;            // rest: 0..9 for the 480 working threads
-        const bool dw_thr = rest < 10;
+        // rest: 0..9 for the 480 working threads; threads 480..511 repeat rest 9's work (same values to the same addresses), so
+        // that no store sits behind a branch: 42 exec-mask branches per thread kept the compiler from staging anything
+        const int c = tid % CH, rest = tid < 10 * CH ? tid / CH : 9;
         const int band = rest % 5, half = rest / 5;
         const int rb = 3 * band;
         const int cg = chunk * CH + c;
-        // window pair columns of this half: local pair l (0..8) <-> window pair (cbase/2 - 1 + l); cbase is even
+        // window pair columns of this half: local pair l (0..8) <-> window pair (cbase/2 - 1 + l); cbase is even.  Only l = 0
+        // (left image border) and l = 8 (right border) can fall outside the window, and then the whole pair is zero padding
         const int cbase = ox0 + 14 * half - wx0;
         const int pb = (cbase >> 1) - 1;
-        const unsigned char* col = E + 4 * c;
+        const bool lok = pb >= 0, rok = pb + 8 < WW / 2;
+        const unsigned char* col = E + 4 * c + (lok ? pb : 0) * ES2;
+        const int o0 = lok ? 0 : -ES2;                      // byte offset of pair l relative to col: o0 + l * ES2 (l >= 1)
         uint32_t P[NR][9];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int wr = rb + r < NROWS ? rb + r : NROWS - 1;     // (band 4 has two output rows: its last window row is unused)
             const unsigned char* rowp = col + (wr * (WW / 2)) * ES2;
+            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(rowp);
+            P[r][0] = lok ? v0 : 0u;
 #pragma unroll
-            for (int l = 0; l < 9; ++l) {
-                const int wp = pb + l;
-                const bool pok = wp >= 0 && wp < WW / 2;
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (pok ? wp : 0) * ES2);
-                P[r][l] = pok ? v : 0u;
-            }
+            for (int l = 1; l < 8; ++l) P[r][l] = *reinterpret_cast<const uint32_t*>(rowp + o0 + l * ES2);
+            const uint32_t v8 = *reinterpret_cast<const uint32_t*>(rowp + o0 + (rok ? 8 : 7) * ES2);
+            P[r][8] = rok ? v8 : 0u;
         }
-        float psum = 0.f;
+        f2 psum2 = {0.f, 0.f};
         _Float16* dg = a.D + (((size_t)b * HIMG + oy0 + rb) * HIMG + ox0 + 14 * half) * CE + cg;
 #pragma unroll
         for (int ro = 0; ro < 3; ++ro) {
             if (rb + ro < 14) {
                 float acc[14];
-#pragma unroll
-                for (int j = 0; j < 14; ++j) acc[j] = dbias;
 #pragma unroll
                 for (int ky = 0; ky < KSD; ++ky) {
                     const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
@@ -3342,19 +3373,23 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                         for (int j = 0; j < 14; ++j) {
                             // local pair of output column j: k5 -> (j>>1) + ip; k3 -> even j: (j>>1) + ip, odd j: (j>>1) + 1 + ip
                             const int l = (KSD == 5 || !(j & 1)) ? (j >> 1) + ip : (j >> 1) + 1 + ip;
-                            acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][l]),
-                                                            *reinterpret_cast<const h2*>(&wq[j & 1][ip]), acc[j], false);
+                            if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ro + ky][l], wq[j & 1][ip], dbias);
+                            else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][l]),
+                                                                 *reinterpret_cast<const h2*>(&wq[j & 1][ip]), acc[j], false);
                         }
                 }
                 silu_scaled_staged(acc);
 #pragma unroll
-                for (int j = 0; j < 14; ++j) {
-                    psum += acc[j];
-                    if (dw_thr) dg[((size_t)ro * HIMG + j) * CE] = (_Float16)acc[j];
+                for (int j = 0; j < 14; j += 2) {
+                    const f2 v = {acc[j], acc[j + 1]};
+                    psum2 = psum2 + v;
+                    const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);     // one conversion per two outputs, low / high half stores
+                    reinterpret_cast<uint16_t*>(dg)[((size_t)ro * HIMG + j) * CE] = (uint16_t)hv;
+                    reinterpret_cast<uint16_t*>(dg)[((size_t)ro * HIMG + j + 1) * CE] = (uint16_t)(hv >> 16);
                 }
             }
         }
-        if (dw_thr) pred[rest * CH + c] = psum;
+        pred[rest * CH + c] = psum2.x + psum2.y;
     }
     T7_BAR();
     if (tid < CH) {
@@ -3435,23 +3470,24 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
         for (int i = 0; i < 3 * KSD; ++i) raw[i] = a.dwp[(size_t)i * CE + cg_dw];
         dbias = a.bdw[cg_dw];
         PIN_VMEM();
+        f4 ba4[3];   // the bias as a ready accumulator operand (see mbt_kernel)
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) ba4[nf] = f4{ba[nf], ba[nf], ba[nf], ba[nf]};
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             if (wave + 8 * i >= NPF) continue;   // wave-uniform
             h8 xb[CKS];
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
-                const uint32_t keep = (32 * ks + 8 * q < Cin) ? 0xffffffffu : 0u;
-                const u4v mk = {xr[i][ks].x & keep, xr[i][ks].y & keep, xr[i][ks].z & keep, xr[i][ks].w & keep};
-                xb[ks] = *reinterpret_cast<const h8*>(&mk);
+                xb[ks] = *reinterpret_cast<const h8*>(&xr[i][ks]);   // (zero-padded K columns: finite re-reads x zero weight rows)
             }
             const int pair0 = 8 * (wave + 8 * i) + 2 * q;
             float t[12];   // the three output fragments' accumulators: SiLU staged over all twelve
 #pragma unroll
             for (int nf = 0; nf < 3; ++nf) {
-                f4 acc = {ba[nf], ba[nf], ba[nf], ba[nf]};
+                f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0], wa[nf][0], ba4[nf], 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
+                for (int ks = 1; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
             }
@@ -3469,27 +3505,29 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
     }
     T7_BAR();
     // ---------------- depthwise, stride 2 ----------------
-    {
-        const int c = tid % CH, orow = tid / CH;            // orow 0..6 work, 7..10 idle
-        const bool dw_thr = orow < 7;
-        const int orc = dw_thr ? orow : 0;
+    // 7 output rows x 48 channels = 336 threads: waves 6 and 7 have nothing to do and skip the phase (their copy of the work used
+    // to cost the vector port a quarter of it); the lanes of wave 5 past thread 335 repeat row 6 (same values, same addresses),
+    // so no store sits behind a branch
+    if (wave < 6) {
+        const int c = tid % CH, orow = tid < 7 * CH ? tid / CH : 6;
         const int cg = chunk * CH + c;
-        const unsigned char* col = E + 4 * c;
+        // only window pair l = 0 (left image border: pbase = -1) can fall outside the window on the left, only the last one on
+        // the right; the whole pair is zero padding then
+        const bool lok = pbase >= 0, rok = pbase + NPR - 1 < WW / 2;
+        const unsigned char* col = E + 4 * c + (lok ? pbase : 0) * ES2;
+        const int o0 = lok ? 0 : -ES2;
         uint32_t P[KSD][NPR];
 #pragma unroll
         for (int ky = 0; ky < KSD; ++ky) {
-            const unsigned char* rowp = col + ((2 * orc + ky) * (WW / 2)) * ES2;
+            const unsigned char* rowp = col + ((2 * orow + ky) * (WW / 2)) * ES2;
+            const uint32_t v0 = *reinterpret_cast<const uint32_t*>(rowp);
+            P[ky][0] = lok ? v0 : 0u;
 #pragma unroll
-            for (int l = 0; l < NPR; ++l) {
-                const int wp = pbase + l;
-                const bool pok = wp >= 0 && wp < WW / 2;
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + (pok ? wp : 0) * ES2);
-                P[ky][l] = pok ? v : 0u;
-            }
+            for (int l = 1; l < NPR - 1; ++l) P[ky][l] = *reinterpret_cast<const uint32_t*>(rowp + o0 + l * ES2);
+            const uint32_t vl = *reinterpret_cast<const uint32_t*>(rowp + o0 + (rok ? NPR - 1 : NPR - 2) * ES2);
+            P[ky][NPR - 1] = rok ? vl : 0u;
         }
         float acc[14];
-#pragma unroll
-        for (int j = 0; j < 14; ++j) acc[j] = dbias;
 #pragma unroll
         for (int ky = 0; ky < KSD; ++ky) {
             const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
@@ -3499,18 +3537,23 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
 #pragma unroll
             for (int ip = 0; ip < NIP; ++ip)
 #pragma unroll
-                for (int j = 0; j < 14; ++j)
-                    acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ip]), acc[j], false);
+                for (int j = 0; j < 14; ++j) {
+                    if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ip], dbias);
+                    else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ip]), acc[j], false);
+                }
         }
-        float psum = 0.f;
-        _Float16* dg = a.D + (((size_t)b * HOUT + oy0 + orc) * HOUT + ox0) * CE + cg;
+        f2 psum2 = {0.f, 0.f};
+        uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * HOUT + oy0 + orow) * HOUT + ox0) * CE + cg);
         silu_scaled_staged(acc);
 #pragma unroll
-        for (int j = 0; j < 14; ++j) {
-            psum += acc[j];
-            if (dw_thr) dg[(size_t)j * CE] = (_Float16)acc[j];
+        for (int j = 0; j < 14; j += 2) {
+            const f2 v = {acc[j], acc[j + 1]};
+            psum2 = psum2 + v;
+            const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);
+            dg[(size_t)j * CE] = (uint16_t)hv;
+            dg[(size_t)(j + 1) * CE] = (uint16_t)(hv >> 16);
         }
-        if (dw_thr) pred[orow * CH + c] = psum;
+        pred[orow * CH + c] = psum2.x + psum2.y;
     }
     T7_BAR();
     if (tid < CH) {
