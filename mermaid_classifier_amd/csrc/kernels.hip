@@ -1692,6 +1692,8 @@ static __device__ __forceinline__ T gload(const GLOBAL_AS void* base, unsigned b
 // No global data is exchanged between the threads of this kernel, so the LDS-only form is sufficient.
 #define T7_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// SiLU of a depthwise output row inside tail7's rounds (staged: all exponentials, packed adds, reciprocals, packed products)
+#define DW_SILU(acc) silu_scaled_staged(acc)
 __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2246,7 +2248,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         const bool fc2_thr = tid < 288;
         const int t2 = fc2_thr ? tid : 0;
         float brv = 0.f;
-        auto dw_phase = [&](auto ks_tag) {
+        auto dw_phase = [&](auto ks_tag) __attribute__((always_inline)) {
             constexpr int KS = decltype(ks_tag)::value, R = KS / 2, NP = KS == 5 ? 3 : 2;
             auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[2 * KS * NP]) {
 #pragma unroll
@@ -2270,7 +2272,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             // first pixel pair an output column reads
             auto first_pair = [](int ox) { return (KS == 5 || !(ox & 1)) ? (ox >> 1) - 1 : (ox >> 1); };
             // one full round: thread = one expanded channel c, all 49 pixels
-            auto dw_round = [&](int c, const uint32_t (&raw)[15], float bias) {
+            auto dw_round = [&](int c, const uint32_t (&raw)[15], float bias) __attribute__((always_inline)) {
                 uint32_t wp[2 * KS * NP];
                 tap_pairs(raw, wp);
                 unsigned char* col = ED + 2 * c;
@@ -2284,14 +2286,14 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                         if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp + 1) * T7_ES);
                         P[y * 4 + pp] = lo | (hi << 16);
                     }
-                float psum = 0.f;
+                f2 psum2 = {0.f, 0.f};
+                float psum1 = 0.f;
 #pragma unroll
                 for (int oy = 0; oy < 7; ++oy) {
                     // the seven outputs of a row advance together (ox innermost): consecutive v_dot2c go to different
-                    // accumulators, so no dependent-issue stalls
+                    // accumulators, so no dependent-issue stalls; the first tap of each takes the bias as its addend
                     float acc[7];
-#pragma unroll
-                    for (int ox = 0; ox < 7; ++ox) acc[ox] = bias;
+                    bool started[7] = {false, false, false, false, false, false, false};
 #pragma unroll
                     for (int ky = 0; ky < KS; ++ky) {
                         const int iy = oy - R + ky;
@@ -2302,19 +2304,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                             for (int ox = 0; ox < 7; ++ox) {
                                 const int xpc = first_pair(ox) + ip;
                                 if (xpc < 0 || xpc > 3) continue;
-                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
-                                                                 *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * NP + ip]),
-                                                                 acc[ox], false);
+                                if (!started[ox]) { acc[ox] = dot2_from(P[iy * 4 + xpc], wp[(ky * 2 + (ox & 1)) * NP + ip], bias); started[ox] = true; }
+                                else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[iy * 4 + xpc]),
+                                                                      *reinterpret_cast<const h2*>(&wp[(ky * 2 + (ox & 1)) * NP + ip]),
+                                                                      acc[ox], false);
                             }
                     }
+                    DW_SILU(acc);
 #pragma unroll
-                    for (int ox = 0; ox < 7; ++ox) {
-                        const float y = silu_scaled(acc[ox]);
-                        psum += y;
-                        *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
+                    for (int ox = 0; ox < 6; ox += 2) {
+                        const f2 v = {acc[ox], acc[ox + 1]};
+                        psum2 = psum2 + v;
+                        const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                        *reinterpret_cast<uint16_t*>(col + (oy * 7 + ox) * T7_ES) = (uint16_t)hv;
+                        *reinterpret_cast<uint16_t*>(col + (oy * 7 + ox + 1) * T7_ES) = (uint16_t)(hv >> 16);
                     }
+                    psum1 += acc[6];
+                    *reinterpret_cast<_Float16*>(col + (oy * 7 + 6) * T7_ES) = (_Float16)acc[6];
                 }
-                pooled[c] = psum;
+                pooled[c] = (psum2.x + psum2.y) + psum1;
             };
             // The depthwise phase is VALU / LDS work with the vector-memory path idle: everything the next phases stream is
             // requested here, in the order it will be consumed, and PINNED (sched_barrier) -- left alone the scheduler sinks
@@ -2365,14 +2373,14 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                     }
                 }
                 T7_BAR();
-                float psum = 0.f;
+                f2 psum2 = {0.f, 0.f};
+                float psum1 = 0.f;
 #pragma unroll
                 for (int ro = 0; ro < 2; ++ro) {
                     const int oy = rb + ro;
                     if (oy < 7) {
                         float acc[7];
-#pragma unroll
-                        for (int ox = 0; ox < 7; ++ox) acc[ox] = biasA;
+                        bool started[7] = {false, false, false, false, false, false, false};
 #pragma unroll
                         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -2381,19 +2389,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                                 for (int ox = 0; ox < 7; ++ox) {
                                     const int xpc = first_pair(ox) + ip;
                                     if (xpc < 0 || xpc > 3) continue;
-                                    acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[(ro + ky) * 4 + xpc]),
-                                                                     *reinterpret_cast<const h2*>(&wpA[(ky * 2 + (ox & 1)) * NP + ip]),
-                                                                     acc[ox], false);
+                                    if (!started[ox]) { acc[ox] = dot2_from(P[(ro + ky) * 4 + xpc], wpA[(ky * 2 + (ox & 1)) * NP + ip], biasA); started[ox] = true; }
+                                    else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[(ro + ky) * 4 + xpc]),
+                                                                          *reinterpret_cast<const h2*>(&wpA[(ky * 2 + (ox & 1)) * NP + ip]),
+                                                                          acc[ox], false);
                                 }
+                        DW_SILU(acc);
 #pragma unroll
-                        for (int ox = 0; ox < 7; ++ox) {
-                            const float y = silu_scaled(acc[ox]);
-                            psum += y;
-                            *reinterpret_cast<_Float16*>(col + (oy * 7 + ox) * T7_ES) = (_Float16)y;
+                        for (int ox = 0; ox < 6; ox += 2) {
+                            const f2 v = {acc[ox], acc[ox + 1]};
+                            psum2 = psum2 + v;
+                            const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                            *reinterpret_cast<uint16_t*>(col + (oy * 7 + ox) * T7_ES) = (uint16_t)hv;
+                            *reinterpret_cast<uint16_t*>(col + (oy * 7 + ox + 1) * T7_ES) = (uint16_t)(hv >> 16);
                         }
+                        psum1 += acc[6];
+                        *reinterpret_cast<_Float16*>(col + (oy * 7 + 6) * T7_ES) = (_Float16)acc[6];
                     }
                 }
-                part[p4 * 128 + cl] = psum;
+                part[p4 * 128 + cl] = (psum2.x + psum2.y) + psum1;
                 T7_BAR();
                 if (tid < 128) pooled[1024 + tid] = ((part[tid] + part[128 + tid]) + part[256 + tid]) + part[384 + tid];
             }
@@ -2619,8 +2633,11 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     constexpr int R = KSD / 2, NP = KSD == 5 ? 3 : 2;
     static_assert(CE % CH == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* E = smem;
-    float* pband = reinterpret_cast<float*>(E + 98 * ES2);   // [5][96]
+    // Zero rows above and below the image (ZT / ZB input rows of 7 pairs): a depthwise window row outside the image reads zeros
+    // instead of being selected to zero register by register (35-49 v_cndmask per thread and chunk).  Written once, below.
+    constexpr int ZT = ST == 1 ? R : 1, ZB = ST == 1 ? R + 1 : 4;
+    unsigned char* E = smem + ZT * 7 * ES2;                  // pair row 0 of the image
+    float* pband = reinterpret_cast<float*>(smem + (98 + 7 * (ZT + ZB)) * ES2);   // [5][96]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
@@ -2634,15 +2651,21 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
     const int npf = wave < 5 ? 2 : 1;
     const int pf0 = wave < 5 ? 2 * wave : wave + 5;
     const GLOBAL_AS _Float16* xgp = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * Cin;
-    // depthwise role of this thread: channel cd of the chunk, output rows rb .. rb+2 (band 4: rows 12, 13)
-    const int band = tid / CH, cd = tid - band * CH;
-    const bool dw_thr = tid < NBAND * CH;
+    // depthwise role of this thread: channel cd of the chunk, output rows rb .. rb+2 (band 4: rows 12, 13).  Threads past the
+    // last band repeat its work (same values to the same addresses): no store sits behind a branch
+    const int band0 = tid / CH, cd = tid - band0 * CH;
+    const int band = band0 < NBAND ? band0 : NBAND - 1;
     const int rb = 3 * band;
+    for (int e = tid; e < (ZT + ZB) * 7 * (ES2 / 16); e += 512) {
+        const int row = e / (ES2 / 16), c16 = e - row * (ES2 / 16);
+        unsigned char* zr = smem + (row < ZT * 7 ? row : row + 98) * ES2 + 16 * c16;
+        *reinterpret_cast<uint4*>(zr) = uint4{0u, 0u, 0u, 0u};
+    }
 #pragma unroll 1
     for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
         // taps and bias of this thread's channel: requested now, used after the expand phase
         uint32_t raw[15];
-        const int cg = chunk * CH + (dw_thr ? cd : 0);
+        const int cg = chunk * CH + cd;
 #pragma unroll
         for (int i = 0; i < 3 * KSD; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * CE + cg) * 4u);
         const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
@@ -2688,12 +2711,12 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                     PIN_VMEM();
                     // un-swapped MFMA (pixels = rows, channels = columns): lane (m, q) gets channel 16 nf + m of pixels
                     // 16 pf + 4q .. +3 = two ready-made pixel pairs (same dot products, same k order as the swapped form)
-                    const f4 bv = {bs, bs, bs, bs};
+                    const f4 bv = {bs, bs, bs, bs};   // the first MFMA reads it as its addend: no copy per accumulator
                     f4 acc[NPFW];
 #pragma unroll
-                    for (int i = 0; i < NPFW; ++i) acc[i] = bv;
+                    for (int i = 0; i < NPFW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[i][0], wc[0], bv, 0, 0, 0);
 #pragma unroll
-                    for (int ks = 0; ks < CKS; ++ks)
+                    for (int ks = 1; ks < CKS; ++ks)
 #pragma unroll
                         for (int i = 0; i < NPFW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[i][ks], wc[ks], acc[i], 0, 0, 0);
                     float t[4 * NPFW];
@@ -2719,31 +2742,24 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         }
         T7_BAR();
         // ---------------- depthwise ----------------
-        float psum = 0.f;
         {
             constexpr int NR = ST == 1 ? 3 + 2 * R : 7;   // input rows of a band (3 output rows; stride 2: 2 output rows)
-            const unsigned char* col = E + 4 * cd;
+            const unsigned char* col = E + 4 * cd + ((ST == 1 ? rb - R : 4 * band - 1) * 7) * ES2;   // (may start in the zero rows)
             uint32_t P[NR][7];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int iy = (ST == 1 ? rb - R : 4 * band - 1) + r;
-                const bool rok = iy >= 0 && iy < 14;
-                const unsigned char* rowp = col + (rok ? iy : 0) * (7 * ES2);
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int pp = 0; pp < 7; ++pp) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
-                    P[r][pp] = rok ? v : 0u;
-                }
-            }
-            _Float16* dg = a.D + (size_t)b * HWO * CE + chunk * CH + cd;
+                for (int pp = 0; pp < 7; ++pp) P[r][pp] = *reinterpret_cast<const uint32_t*>(col + (r * 7 + pp) * ES2);
+            f2 psum2 = {0.f, 0.f};
+            float psum1 = 0.f;
+            uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (size_t)b * HWO * CE + chunk * CH + cd);
             if (ST == 2) {
 #pragma unroll
                 for (int ro = 0; ro < 2; ++ro) {
                     const int oy = 2 * band + ro;
                     if (oy < 7) {
                         float acc[7];
-#pragma unroll
-                        for (int ox = 0; ox < 7; ++ox) acc[ox] = dbias;
+                        bool started[7] = {false, false, false, false, false, false, false};
 #pragma unroll
                         for (int ky = 0; ky < 5; ++ky) {
                             const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
@@ -2754,16 +2770,22 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                                 for (int ox = 0; ox < 7; ++ox) {
                                     const int xpc = ox - 1 + ip;
                                     if (xpc < 0 || xpc > 6) continue;
-                                    acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
-                                                                     *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
+                                    if (!started[ox]) { acc[ox] = dot2_from(P[2 * ro + ky][xpc], wq[ip], dbias); started[ox] = true; }
+                                    else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
+                                                                          *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
                                 }
                         }
                         silu_scaled_staged(acc);
 #pragma unroll
-                        for (int ox = 0; ox < 7; ++ox) {
-                            psum += acc[ox];
-                            if (dw_thr) dg[(size_t)(oy * 7 + ox) * CE] = (_Float16)acc[ox];
+                        for (int ox = 0; ox < 6; ox += 2) {
+                            const f2 v = {acc[ox], acc[ox + 1]};
+                            psum2 = psum2 + v;
+                            const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                            dg[(size_t)(oy * 7 + ox) * CE] = (uint16_t)hv;
+                            dg[(size_t)(oy * 7 + ox + 1) * CE] = (uint16_t)(hv >> 16);
                         }
+                        psum1 += acc[6];
+                        reinterpret_cast<_Float16*>(dg)[(size_t)(oy * 7 + 6) * CE] = (_Float16)acc[6];
                     }
                 }
             } else
@@ -2772,8 +2794,7 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                 const int oy = rb + ro;
                 if (oy < 14) {
                     float acc[14];
-#pragma unroll
-                    for (int ox = 0; ox < 14; ++ox) acc[ox] = dbias;
+                    bool started[14] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false};
 #pragma unroll
                     for (int ky = 0; ky < KSD; ++ky) {
                         // tap pairs of this kernel row: [parity of x][pair]; the shifted variants are derived here (per
@@ -2794,19 +2815,23 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
                                 const int fp = (KSD == 5 || !(ox & 1)) ? (ox >> 1) - 1 : (ox >> 1);
                                 const int xpc = fp + ip;
                                 if (xpc < 0 || xpc > 6) continue;
-                                acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][xpc]),
-                                                                 *reinterpret_cast<const h2*>(&wq[ox & 1][ip]), acc[ox], false);
+                                if (!started[ox]) { acc[ox] = dot2_from(P[ro + ky][xpc], wq[ox & 1][ip], dbias); started[ox] = true; }
+                                else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ro + ky][xpc]),
+                                                                      *reinterpret_cast<const h2*>(&wq[ox & 1][ip]), acc[ox], false);
                             }
                     }
                     silu_scaled_staged(acc);
 #pragma unroll
-                    for (int ox = 0; ox < 14; ++ox) {
-                        psum += acc[ox];
-                        if (dw_thr) dg[(size_t)(oy * 14 + ox) * CE] = (_Float16)acc[ox];
+                    for (int ox = 0; ox < 14; ox += 2) {
+                        const f2 v = {acc[ox], acc[ox + 1]};
+                        psum2 = psum2 + v;
+                        const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                        dg[(size_t)(oy * 14 + ox) * CE] = (uint16_t)hv;
+                        dg[(size_t)(oy * 14 + ox + 1) * CE] = (uint16_t)(hv >> 16);
                     }
                 }
             }
-            if (dw_thr) pband[band * CH + cd] = psum;
+            pband[band * CH + cd] = (psum2.x + psum2.y) + psum1;
         }
         T7_BAR();
         if (tid < CH)
@@ -4495,7 +4520,10 @@ int proj_patch_has(int K, int N, int HW, int res)
 template <int CKS, int KSD, int CE, int ST = 1>
 static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
 {
-    const int lds = 98 * 416 + 5 * 96 * 4 + 512;   // E2 chunk, pool partials of the row bands, scratch words of the expand's masked stores
+    // E2 chunk with its zero rows above and below the image (mid14_kernel's ZT + ZB), pool partials of the row bands, scratch
+    // words of the expand's masked stores
+    constexpr int ZROWS = ST == 1 ? 2 * (KSD / 2) + 1 : 5;
+    const int lds = (98 + 7 * ZROWS) * 416 + 5 * 96 * 4 + 512;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14_kernel<CKS, KSD, CE, ST>),
