@@ -1862,7 +1862,10 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             //      channel x 2 output rows, 7x7 pixel-pair window in registers, v_dot2c) -> silu -> D11[49][672] compact in
             //      LDS + pool sums.  No launch, no D11 / pool tensor in HBM, no second read of them. ----
             constexpr int CH = 96, ES2 = 416;                  // E2[98 pixel pairs][96 channels], one dword per pair (as in mid14_kernel)
-            unsigned char* EB = ED + T7_PIX * T7_DS11;         // expanded chunk, behind the compact D11
+            // expanded chunk, behind the compact D11, with one zero input row above the image and four below it (the rows a stride-2
+            // window reaches outside: read as zeros instead of being selected to zero register by register); 131.4 KB in all, X's
+            // region (unused until block 11's project) included
+            unsigned char* EB = ED + T7_PIX * T7_DS11 + 7 * ES2;
             float* pband = part;                               // [4][96] pool partials of the row bands
             const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.pre_wexp);
             const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.pre_bexp);
@@ -1887,8 +1890,11 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 const int pix = e / 12, oc = e - pix * 12;
                 *reinterpret_cast<uint4*>(ED + pix * T7_DS11 + 1344 + oc * 16) = uint4{0u, 0u, 0u, 0u};
             }
-            const int band = tid / CH, cd = tid - band * CH;
-            const bool dw_thr = tid < 4 * CH;
+            for (int e = tid; e < 35 * (ES2 / 16); e += 512) {
+                const int row = e / (ES2 / 16), c16 = e - row * (ES2 / 16);
+                *reinterpret_cast<uint4*>(EB + (row < 7 ? row - 7 : row + 91) * ES2 + 16 * c16) = uint4{0u, 0u, 0u, 0u};
+            }
+            const int band = tid / CH, cd = tid - band * CH;   // waves 6 and 7 (band >= 4) sit the depthwise phase out
             // Weight fragments AND the bias of the next output fragment are requested one fragment ahead (across the chunk
             // boundary too; fragment 42 = fragment 41 re-read, unused), bias first: a load needed now is never queued behind
             // loads needed later (vmcnt retires in order).  The wave's role (two pixel fragments or one) is a template argument
@@ -1944,35 +1950,29 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 #pragma unroll 1
             for (int chunk = 0; chunk < 7; ++chunk) {
                 uint32_t raw[15];
-                const int cg = chunk * CH + (dw_thr ? cd : 0);
+                const int cg = chunk * CH + cd;   // (waves 6, 7: some channel of the block, unused)
 #pragma unroll
                 for (int i = 0; i < 15; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * 672 + cg) * 4u);
                 const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
                 if (npf == 2) expand_chunk(std::integral_constant<int, 2>{}, chunk);
                 else expand_chunk(std::integral_constant<int, 1>{}, chunk);
                 T7_BAR();
-                float psum = 0.f;
-                {
-                    const unsigned char* col = EB + 4 * cd;
+                if (wave < 6) {   // 4 bands x 96 channels = waves 0..5 exactly
+                    const unsigned char* col = EB + 4 * cd + ((4 * band - 1) * 7) * ES2;   // (band 0 starts in the zero row)
                     uint32_t P[7][7];
 #pragma unroll
-                    for (int r = 0; r < 7; ++r) {
-                        const int iy = 4 * band - 1 + r;
-                        const bool rok = iy >= 0 && iy < 14;
-                        const unsigned char* rowp = col + (rok ? iy : 0) * (7 * ES2);
+                    for (int r = 0; r < 7; ++r)
 #pragma unroll
-                        for (int pp = 0; pp < 7; ++pp) {
-                            const uint32_t v = *reinterpret_cast<const uint32_t*>(rowp + pp * ES2);
-                            P[r][pp] = rok ? v : 0u;
-                        }
-                    }
+                        for (int pp = 0; pp < 7; ++pp) P[r][pp] = *reinterpret_cast<const uint32_t*>(col + (r * 7 + pp) * ES2);
+                    f2 psum2 = {0.f, 0.f};
+                    float psum1 = 0.f;
+                    unsigned char* dcol = ED + (chunk * CH + cd) * 2;
 #pragma unroll
                     for (int ro = 0; ro < 2; ++ro) {
                         const int oy = 2 * band + ro;
                         if (oy < 7) {
                             float acc[7];
-#pragma unroll
-                            for (int ox = 0; ox < 7; ++ox) acc[ox] = dbias;
+                            bool started[7] = {false, false, false, false, false, false, false};
 #pragma unroll
                             for (int ky = 0; ky < 5; ++ky) {
                                 const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
@@ -1983,19 +1983,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                                     for (int ox = 0; ox < 7; ++ox) {
                                         const int xpc = ox - 1 + ip;
                                         if (xpc < 0 || xpc > 6) continue;
-                                        acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
-                                                                         *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
+                                        if (!started[ox]) { acc[ox] = dot2_from(P[2 * ro + ky][xpc], wq[ip], dbias); started[ox] = true; }
+                                        else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
+                                                                              *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
                                     }
                             }
                             silu_scaled_staged(acc);
 #pragma unroll
-                            for (int ox = 0; ox < 7; ++ox) {
-                                psum += acc[ox];
-                                if (dw_thr) *reinterpret_cast<_Float16*>(ED + (oy * 7 + ox) * T7_DS11 + (chunk * CH + cd) * 2) = (_Float16)acc[ox];
+                            for (int ox = 0; ox < 6; ox += 2) {
+                                const f2 v = {acc[ox], acc[ox + 1]};
+                                psum2 = psum2 + v;
+                                const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                                *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox) * T7_DS11) = (uint16_t)hv;
+                                *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox + 1) * T7_DS11) = (uint16_t)(hv >> 16);
                             }
+                            psum1 += acc[6];
+                            *reinterpret_cast<_Float16*>(dcol + (oy * 7 + 6) * T7_DS11) = (_Float16)acc[6];
                         }
                     }
-                    if (dw_thr) pband[band * CH + cd] = psum;
+                    pband[band * CH + cd] = (psum2.x + psum2.y) + psum1;
                 }
                 T7_BAR();
                 if (tid < CH) pooled[chunk * CH + tid] = ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid];
@@ -2177,14 +2183,24 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             unsigned char* const scratch = reinterpret_cast<unsigned char*>(part) + lane * 8;   // masked rows store here (part is idle now)
             float tp[16], ep[16];   // previous fragment: accumulators / SiLU intermediates
             int nfp = 0;
-            // vector instruction number `op` of the epilogue of the previous fragment (68 in all)
+            f4 bvn_cur = bvn;
+            // vector operation number `op` of the epilogue of the previous fragment (52 in all: the adds and the products run two
+            // values per instruction)
             auto epi_op = [&](int op) {
                 if (op < 16) ep[op] = __builtin_amdgcn_exp2f(-tp[op]);
-                else if (op < 32) ep[op - 16] = 1.0f + ep[op - 16];
-                else if (op < 48) ep[op - 32] = __builtin_amdgcn_rcpf(ep[op - 32]);
-                else if (op < 64) tp[op - 48] = tp[op - 48] * ep[op - 48];
-                else if (op < 68) {
-                    const int pf = op - 64;
+                else if (op < 24) {
+                    const int i2 = 2 * (op - 16);
+                    f2 v = {ep[i2], ep[i2 + 1]};
+                    v = v + (f2){1.0f, 1.0f};
+                    ep[i2] = v.x; ep[i2 + 1] = v.y;
+                } else if (op < 40) ep[op - 24] = __builtin_amdgcn_rcpf(ep[op - 24]);
+                else if (op < 48) {
+                    const int i2 = 2 * (op - 40);
+                    f2 v = {tp[i2], tp[i2 + 1]}, r = {ep[i2], ep[i2 + 1]};
+                    v = v * r;
+                    tp[i2] = v.x; tp[i2 + 1] = v.y;
+                } else if (op < 52) {
+                    const int pf = op - 48;
                     h4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (_Float16)tp[4 * pf + j];
@@ -2201,7 +2217,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 if (i < 9) {
 #pragma unroll
                     for (int ks = 0; ks < 6; ++ks) wc[ks] = wn[ks];
-                    const f4 bv = bvn;
+                    bvn_cur = bvn;
                     if (i + 1 < 9) {
                         const int nfn = 9 * wave + (ir + 1 >= 9 ? ir + 1 - 9 : ir + 1);
                         bvn = gload<f4>(W.bexp, (unsigned)(16 * nfn + 4 * q) * 4u);
@@ -2209,16 +2225,16 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                         for (int ks = 0; ks < 6; ++ks) wn[ks] = gload<h8>(W.wexp, (unsigned)(((nfn * 6 + ks) * 64 + lane) * 16));
                     }
                     PIN_VMEM();
-#pragma unroll
-                    for (int pf = 0; pf < 4; ++pf) acc[pf] = bv;
                 }
+                const f4 bvc = bvn_cur;
 #pragma unroll
                 for (int slot = 0; slot < 24; ++slot) {
-                    if (i < 9) acc[slot & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[slot >> 2], xb[slot & 3][slot >> 2], acc[slot & 3], 0, 0, 0);
+                    // (the first k-step takes the bias vector as its addend: no copy per accumulator)
+                    if (i < 9) acc[slot & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[slot >> 2], xb[slot & 3][slot >> 2], slot < 4 ? bvc : acc[slot & 3], 0, 0, 0);
                     if (i > 0) {
 #pragma unroll
                         for (int v = 0; v < 3; ++v)
-                            if (3 * slot + v < 68) epi_op(3 * slot + v);
+                            if (3 * slot + v < 52) epi_op(3 * slot + v);
                     }
                     if (i > 0 && i < 9) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
