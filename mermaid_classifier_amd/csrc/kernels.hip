@@ -3112,7 +3112,10 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
     // ---------------- block 0's gate + project, ONCE per tile: the projected fragments (4 fp16 per lane and fragment) stay in
     // registers and feed the expand of all three 32-channel chunks.  (One workgroup per (tile, chunk) read block 0's depthwise output
     // three times -- 320 MB fetched per 128 patches against 103 MB -- and redid the gate + project MFMA per chunk.) ----------------
-    bool okp[8][2];   // validity of this lane's two OUTPUT pairs (positions 16 pf + 4q .. +3): inside the window and the image
+    // Positions outside the image (row 112 / column 112: TF-same pads bottom and right only) are NOT zeroed in E: they hold the
+    // expand of some in-image pixel, and the only depthwise taps that read them -- kernel row 2 of output row 55, kernel column 2
+    // of output column 55 -- get zero weights in the threads that own those outputs (five selects per thread and chunk instead of
+    // a select per stored pair and the bookkeeping of which pairs lie outside).
     uint2 xbp[8];     // block 0's output fragment (k = 4q .. 4q+3 of 16), rounded as the separate path stores it
     {
         u4v xr[8];
@@ -3124,13 +3127,6 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
             const int iy = iy0 + r, ix = ix0 + c;
             const bool ok = pf < NPF && p < NPOS && iy < 112 && ix < 112;
             xr[i] = gload<u4v>(xg, (unsigned)((((ok ? iy : 0) * 112 + (ok ? ix : 0)) * 32 + 8 * q) * 2));
-            const int p0 = 16 * pf + 4 * q;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pp = p0 + 2 * h;                 // even position: the pair (pp, pp+1) lies in one row
-                const int pr = pp / WC, pc = pp - pr * WC;
-                okp[i][h] = pf < NPF && pp < NPOS && iy0 + pr < 112 && ix0 + pc < 112;   // 112 is even: a pair is in or out as a whole
-            }
         }
         const h8 wpre = *reinterpret_cast<const h8*>(a.pre_w + lane * 8);
         const f4 bpre = *reinterpret_cast<const f4*>(a.pre_b + 4 * q);
@@ -3192,10 +3188,9 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
             for (int nf = 0; nf < 2; ++nf) {
                 const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
                 const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
-                const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
                 unsigned char* dst = E + (8 * (wave + 8 * i) + 2 * q) * ES2 + (16 * nf + m) * 4;   // first output pair: (16 pf + 4 q) / 2
-                *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
-                *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
+                *reinterpret_cast<h2*>(dst) = p0;
+                *reinterpret_cast<h2*>(dst + ES2) = p1;
             }
         }
         if (chunk + 1 < 3) request_chunk(chunk + 1);   // lands during the depthwise phase
@@ -3204,13 +3199,16 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
         {
             const int c = tid & 31, orow = (tid >> 5) & 7, half = tid >> 8;
             const int cg = chunk * 32 + c;
-            uint32_t wq[3][2];
+            uint32_t wq[3][2], wql[3];   // wql: the (k2, 0) pair as output column 13 of the half sees it
+            const bool last_row = oy0 + orow == 55, last_col = tx == 1 && half == 1;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const float k0 = kdw[ky * 3 + 0], k1 = kdw[ky * 3 + 1], k2 = kdw[ky * 3 + 2];
                 h2 w0 = {(_Float16)k0, (_Float16)k1}, w1 = {(_Float16)k2, (_Float16)0.0f};
                 wq[ky][0] = *reinterpret_cast<uint32_t*>(&w0);
                 wq[ky][1] = *reinterpret_cast<uint32_t*>(&w1);
+                if (ky == 2) { wq[ky][0] = last_row ? 0u : wq[ky][0]; wq[ky][1] = last_row ? 0u : wq[ky][1]; }
+                wql[ky] = last_col ? 0u : wq[ky][1];
             }
             const float dbias_c = dbias;
             if (chunk + 1 < 3) request_taps(chunk + 1);
@@ -3229,8 +3227,9 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
                 for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
                     for (int j = 0; j < 14; ++j) {
-                        if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ky][ip], dbias_c);
-                        else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]),
+                        const uint32_t wt = (ip == 1 && j == 13) ? wql[ky] : wq[ky][ip];
+                        if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wt, dbias_c);
+                        else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wt),
                                                              acc[j], false);
                     }
             f2 psum2 = {0.f, 0.f};
