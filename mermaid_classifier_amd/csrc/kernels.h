@@ -22,6 +22,7 @@ struct GemmArgs {
     int HW;              // rows per patch
     const _Float16* res; // [M][N] or null
     float* gap_out;      // EPI_GAP: [patches][N]
+    int x_plane_rows;    // thin_proj only: X is [K/32][x_plane_rows][32] planes (0: rows of K)
     float inv_hw;
 };
 
@@ -112,7 +113,8 @@ struct Mb1Args {
     const float* bexp;        // [96]
     const float* wdw;         // [9][96] depthwise taps (fp32, tap-major)
     const float* bdw;         // [96]
-    _Float16* D;              // [B][56][56][96]
+    _Float16* D;              // [B][56][56][96], or planar: [3][B * 56 * 56][32]
+    int planar;
     float* pool;              // [B][14][96]
     int B;
 };

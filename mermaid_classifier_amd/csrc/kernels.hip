@@ -415,8 +415,8 @@ template <int KSTEPS, bool RES>
 __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restrict__ X, int K, const _Float16* __restrict__ Wp,
                                                         const float* __restrict__ bias, _Float16* __restrict__ Y, int N,
                                                         const float* __restrict__ gate, int HW, int frags_per_wg,
-                                                        const _Float16* __restrict__ res)
-{
+                                                        const _Float16* __restrict__ res, int plane_rows)
+{   // plane_rows > 0: X is [K / 32 planes][plane_rows][32] (mb1_kernel<true>'s output), k-step ks reads plane ks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     const int b = blockIdx.y;
@@ -445,7 +445,8 @@ __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restri
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const int k = ks * 32 + q * 8;
             h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (k < K) v = *reinterpret_cast<const h8*>(xb + row * K + k);
+            if (k < K) v = plane_rows ? *reinterpret_cast<const h8*>(X + (((size_t)ks * plane_rows + (size_t)b * HW + row) * 32 + q * 8))
+                                      : *reinterpret_cast<const h8*>(xb + row * K + k);
             dst[ks] = v;
         }
         if (RES) {
@@ -3095,6 +3096,12 @@ __global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
 //            two v_dot2c per kernel row and output ((k0,k1) on pair j, (k2,0) on pair j+1), silu, fp16 to HBM,
 //            pool sums through LDS -> pool[patch][tile][96].
 // ---------------------------------------------------------------------------------------------
+// PLANAR: the depthwise output goes to D as three planes [chunk][B * 56 * 56][32] instead of [B][56][56][96].  A workgroup
+// produces its three 32-channel chunks ~25 us apart; interleaved, the 64 bytes it writes per pixel and chunk are a third of a
+// 192-byte pixel, the 128-byte lines stay partial until another chunk (long evicted) completes them, and WRITE_SIZE was 1.7 x the
+// tensor (131 MB vs 77 MB per 128 patches).  In a plane the two 64-byte halves of a line are consecutive outputs of one thread.
+// thin_proj_kernel reads the planes (a k-step of its MFMA is exactly one plane).
+template <bool PLANAR>
 __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: two workgroups per CU (one: 105 vs 94 us)
 {
     // The window is enumerated with 58 columns (29 pixel pairs; the 58th column is one more real pixel, or zero past the image):
@@ -3233,15 +3240,17 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
                                                              acc[j], false);
                     }
             f2 psum2 = {0.f, 0.f};
-            uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half) * 96 + cg);
+            constexpr int PS = PLANAR ? 32 : 96;   // elements between consecutive pixels
+            const size_t pix = ((size_t)b * 56 + oy0 + orow) * 56 + ox0 + 14 * half;
+            uint16_t* dg = reinterpret_cast<uint16_t*>(PLANAR ? a.D + ((size_t)chunk * a.B * 3136 + pix) * 32 + c : a.D + pix * 96 + cg);
             silu_scaled_staged(acc);
 #pragma unroll
             for (int j = 0; j < 14; j += 2) {
                 const f2 v = {acc[j], acc[j + 1]};
                 psum2 = psum2 + v;
                 const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);
-                dg[(size_t)j * 96] = (uint16_t)hv;
-                dg[(size_t)(j + 1) * 96] = (uint16_t)(hv >> 16);
+                dg[(size_t)j * PS] = (uint16_t)hv;
+                dg[(size_t)(j + 1) * PS] = (uint16_t)(hv >> 16);
             }
             pred[(tid >> 5) * 32 + c] = psum2.x + psum2.y;
         }
@@ -4198,7 +4207,7 @@ int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
 {
     // pack_pw layout with nt = 2, one chunk; whole 16-pixel fragments; 8-channel lanes
     if (a.nt != 2 || a.n_chunks != 1 || a.K > 192 || (a.K & 7) || a.N > 32 || (a.N & 7) || (a.HW & 15) || !a.gate || a.epi != EPI_LINEAR ||
-        a.M != patches * a.HW)
+        a.M != patches * a.HW || (a.x_plane_rows && (a.x_plane_rows != a.M || (a.K & 31))))
         return -15;
     const int nfrag = a.HW / 16;
     int per = (int)(((long)nfrag * patches / 2048 + 3) / 4 * 4);   // fragments per workgroup: ~2048 workgroups, whole rounds of 4 waves
@@ -4207,7 +4216,7 @@ int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
     if (nfrag < per) per = nfrag;
     dim3 grid((nfrag + per - 1) / per, patches);
     const int ks = a.Kp / 32;
-#define TP_GO(KS_, RES_) hipLaunchKernelGGL((thin_proj_kernel<KS_, RES_>), grid, dim3(256), 0, st, a.X, a.K, a.Wp, a.bias, a.Y, a.N, a.gate, a.HW, per, a.res)
+#define TP_GO(KS_, RES_) hipLaunchKernelGGL((thin_proj_kernel<KS_, RES_>), grid, dim3(256), 0, st, a.X, a.K, a.Wp, a.bias, a.Y, a.N, a.gate, a.HW, per, a.res, a.x_plane_rows)
     if (ks == 1 && a.res) TP_GO(1, true);
     else if (ks == 1) TP_GO(1, false);
     else if (ks == 2 && a.res) TP_GO(2, true);
@@ -4594,11 +4603,15 @@ int launch_mb1(const Mb1Args& a, hipStream_t st)
     const int lds = 62 * 8 * 160 + 16 * 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(mb1_kernel, dim3(14, 1, a.B), dim3(512), lds, st, a);   // one workgroup per (tile, patch): walks the three channel chunks
+    // one workgroup per (tile, patch): walks the three channel chunks
+    if (a.planar) hipLaunchKernelGGL(mb1_kernel<true>, dim3(14, 1, a.B), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(mb1_kernel<false>, dim3(14, 1, a.B), dim3(512), lds, st, a);
     LAUNCH_CHECK();
     return 0;
 }

@@ -257,6 +257,7 @@ struct mmc_backbone {
     bool mid14 = false;              // 14x14 blocks: per-patch front half (mid14_kernel) instead of tile/chunk workgroups
     int mid14_last = 8;              // ... for blocks 6..mid14_last
     bool mid14_b11 = false;          // ... and block 11 (5x5 stride 2) on mid14_kernel<4,5,672,2>
+    bool b1_planar = true;           // block 1's depthwise output as 32-channel planes between mb1 and thin_proj (MMC_B1_PLANAR=0)
     bool thin_proj = true;           // B4 blocks 0/1: thin_proj_kernel instead of pw_gemm for the tiny-K project convs (MMC_THIN_PROJ=0)
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
@@ -478,6 +479,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const bool fuse_generic = !is_b0 && !(fuse_env && fuse_env[0] == '0');   // B4: fused expand+depthwise where an instantiation fits
     const int b4_cc14 = [] { const char* e = getenv("MMC_B4_CC14"); return e && atoi(e) == 48 ? 48 : 96; }();   // 5x5 layers at 14x14: 96 measured +1.3 %
     { const char* e = getenv("MMC_THIN_PROJ"); bb->thin_proj = !(e && e[0] == '0'); }
+    { const char* e = getenv("MMC_B1_PLANAR"); bb->b1_planar = !(e && e[0] == '0'); }
     bb->fuse_stem = fuse_enabled;
     const char* pp_env = getenv("MMC_PROJSE");
     const bool projse_enabled = fuse_enabled && !(pp_env && pp_env[0] == '0');
@@ -982,6 +984,14 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
+        // small-K, small-N project on a big image: thin_proj_kernel (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
+        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 3; }();
+        const bool use_thin = bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && B.project.Kp / 32 <= thin_max && B.project.N <= 32 &&
+                              (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136;
+        // block 1's depthwise output as three 32-channel planes between mb1_kernel and thin_proj_kernel (see mb1_kernel); per-tensor
+        // mode keeps the interleaved tensor it hands out (MMC_B1_PLANAR=0 switches the planes off)
+        const bool b1_planar = i == 1 && use_thin && bb->b1_planar && !bb->keep && B.project.K == 96;
+        bool d_planar = false;   // set where mb1_kernel is the producer
         if (i == 11 && bb->tail_full && bb->tail_b11 && !bb->keep) {
             // the whole of block 11, blocks 12..15 and the head conv in ONE launch: from block 10's output to the feature vector
             TailArgs ta{};
@@ -1046,6 +1056,8 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                     Mb1Args m1{};
                     m1.X = y; m1.pre_w = bb->b0_pre_w; m1.pre_b = bb->blk[0].project.b; m1.pre_gate = ws.gate; m1.wexp = bb->b1_exp_pre;
                     m1.bexp = B.expand.b; m1.wdw = B.dw_w; m1.bdw = B.dw_b; m1.D = ws.dwbuf; m1.pool = ws.pool_part; m1.B = n;
+                    m1.planar = b1_planar ? 1 : 0;
+                    d_planar = b1_planar;
                     nparts = 14;
                     snprintf(nm, sizeof nm, "b0.project+b1.mbconv");
                     STEP(nm, "mb1", launch_mb1(m1, st));
@@ -1141,14 +1153,13 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (i == 0 && bb->fuse_b0b1 && stem_fused) continue;   // block 0's project runs inside block 1's kernel
         snprintf(nm, sizeof nm, "b%d.project", i);
         const int pks = B.project.Kp / 32;
-        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 3; }();   // k-steps thin_proj takes (5-6: block 2's project, measured below)
-        if (bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && pks <= thin_max && B.project.N <= 32 &&   // (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
-            (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136) {
+        if (use_thin) {
             // small-K, small-N project on a big image (B4 blocks 0, 1; B0 block 1): stream one patch's fragments per workgroup
             GemmArgs a{};
             a.X = ws.dwbuf; a.M = n * HWo; a.K = B.project.K; a.Wp = B.project.w; a.Kp = B.project.Kp; a.bias = B.project.b; a.Y = y;
             a.N = B.project.N; a.nt = B.project.nt; a.n_chunks = B.project.n_chunks; a.epi = EPI_LINEAR; a.gate = ws.gate; a.HW = HWo;
             a.res = B.skip ? x : nullptr;
+            a.x_plane_rows = d_planar ? n * HWo : 0;
             STEP(nm, "thin_proj", launch_thin_proj(a, n, st));
         } else
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
