@@ -120,6 +120,23 @@ struct Mb1Args {
 };
 int launch_mb1(const Mb1Args& a, hipStream_t st);
 
+// Block 2's gate + project + skip inside block 3's front half (mb3_kernel)
+struct Mb3Args {
+    const _Float16* D2;       // [B][56][56][144] block 2's depthwise output
+    const _Float16* pre_w;    // [2][5][64][8] block 2's project conv as MFMA A fragments (n tile, k-step; rows >= 24 and k >= 144 zero)
+    const float* pre_b;       // [32] (24 used, rest zero)
+    const float* pre_gate;    // [B][144] block 2's squeeze-excite gate
+    const _Float16* pre_res;  // [B][56][56][24] block 2's skip input (block 1's output)
+    const _Float16* wexp;     // [9][64][8] block 3's expand weights as MFMA B fragments, K slots permuted (see mb3_kernel)
+    const float* bexp;        // [144]
+    const uint32_t* dwp;      // [15][144] depthwise taps as fp16 pairs
+    const float* bdw;         // [144]
+    _Float16* D;              // [B][28][28][144]
+    float* pool;              // [B][8][144]
+    int B;
+};
+int launch_mb3(const Mb3Args& a, hipStream_t st);
+
 // Front half of a stride-1 MBConv block on 14x28 output tiles (mbt_kernel: b2, b4)
 struct MbtArgs {
     const _Float16* X;        // [B][H][H][Cin]
