@@ -4151,13 +4151,16 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     wx0 = wx0 < 0 ? 0 : wx0;
     wy1 = wy1 > 112 ? 112 : wy1;
     wx1 = wx1 > 112 ? 112 : wx1;
-    const int ww = wx1 - wx0, wh = wy1 - wy0;
-    const int P = wh * ww;
-    const unsigned wmagic = (65536u + ww - 1) / ww;
+    const int wh = wy1 - wy0;
+    // The stem window is enumerated as a FIXED 18 x 18 grid from (oy0 - 1, ox0 - 1); positions outside the image hold zeros in E
+    // (the depthwise conv's padding) and are skipped by phase 1.  Phase 2 then needs no bounds test, no skipped kernel row and no
+    // address arithmetic (every E read is lane base + immediate), and a depthwise accumulator starts as its first tap's addend.
+    constexpr int P = SD_WIN * SD_WIN;
+    const int dy = wy0 - (oy0 - 1);                  // 1 for the top tiles (window row 0 is above the image)
     // ---- stage the input tile as exact fp16 (u8-128): rows 2*wy0 .. 2*wy1, cols from 2*(16tx-2) so that every
     //      row segment starts on a dword (6*(16tx-2) bytes); 37 rows x 31 dwords (41 pixels), one dword per thread-step
     const int icol0 = 2 * (ox0 - 2);                 // may be -4 for the leftmost tiles (those pixels are never used)
-    const int cshift = 2 * wx0 - icol0;              // staged column of the window's first input pixel (2 or 4)
+    constexpr int cshift = 2;                        // staged column of window column 0's first input pixel: 2 (ox0 - 1) - icol0
     {
         const uint8_t* img = patches + (size_t)b * (224 * 224 * 3);
         const int iy0 = 2 * wy0;
@@ -4197,6 +4200,15 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
             }
         }
         for (int i = tid; i < 9 * 32; i += 256) wl[i] = Wdw[i];
+        if (tx == 0 || ty == 0 || tx == 6 || ty == 6)   // border tiles: zero the window positions outside the image
+            for (int pz = tid; pz < P; pz += 256) {
+                const int py = pz / SD_WIN, px = pz - py * SD_WIN;
+                const int sy = oy0 - 1 + py, sx = ox0 - 1 + px;
+                if (sy < 0 || sy >= 112 || sx < 0 || sx >= 112) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *reinterpret_cast<uint4*>(E + pz * SD_ES + 16 * v) = uint4{0u, 0u, 0u, 0u};
+                }
+            }
     }
     __syncthreads();
     // ---- phase 1: stem conv on the window -> E[p][32] ----
@@ -4207,11 +4219,13 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
         f4 bsv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) bsv[t] = *reinterpret_cast<const f4*>(bias + q * 8 + t * 4);
-        const int MTn = (P + 15) >> 4;
+        constexpr int MTn = (P + 15) >> 4;
         for (int mt = wave; mt < MTn; mt += 4) {
             const int p = mt * 16 + m;
-            const bool ok = p < P;
-            const int py = ok ? (int)(((unsigned)p * wmagic) >> 16) : 0, px = ok ? p - py * ww : 0;
+            const int py0 = p / SD_WIN, px0 = p - py0 * SD_WIN;
+            const int sy = oy0 - 1 + py0, sx = ox0 - 1 + px0;
+            const bool ok = p < P && sy >= 0 && sy < 112 && sx >= 0 && sx < 112;
+            const int py = ok ? py0 - dy : 0, px = ok ? px0 : 1;   // staged rows start at stem row wy0 = oy0 - 1 + dy
             h8 a;
             if (q < 3) {
                 // 8 consecutive halves starting on a dword boundary (6*px + 3*cshift is even): four 32-bit LDS reads
@@ -4259,15 +4273,9 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
         for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
     }
     float acc[4][8];
+    const unsigned char* ebase = E + ((oyl * SD_WIN + oxl) * SD_ES + cg * 16);   // window position (oyl + ky, oxl + xr) = output (oy - 1 + ky, ox - 1 + xr)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[t][j] = bs[j];
-#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy - 1 + ky;
-        if (iy < 0 || iy >= 112) continue;
-        const int rbase = (iy - wy0) * ww - wx0;
         float wk[3][8];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -4278,21 +4286,20 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
         }
 #pragma unroll
         for (int xr = 0; xr < 6; ++xr) {
-            const int ix = ox - 1 + xr;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (ix >= 0 && ix < 112) v = *reinterpret_cast<const uint4*>(E + (rbase + ix) * SD_ES + cg * 16);
+            const uint4 v = *reinterpret_cast<const uint4*>(ebase + (ky * SD_WIN + xr) * SD_ES);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int kx = xr - t;
                 if (kx >= 0 && kx < 3) {
-                    acc[t][0] = fma_mix_lo(v.x, wk[kx][0], acc[t][0]);
-                    acc[t][1] = fma_mix_hi(v.x, wk[kx][1], acc[t][1]);
-                    acc[t][2] = fma_mix_lo(v.y, wk[kx][2], acc[t][2]);
-                    acc[t][3] = fma_mix_hi(v.y, wk[kx][3], acc[t][3]);
-                    acc[t][4] = fma_mix_lo(v.z, wk[kx][4], acc[t][4]);
-                    acc[t][5] = fma_mix_hi(v.z, wk[kx][5], acc[t][5]);
-                    acc[t][6] = fma_mix_lo(v.w, wk[kx][6], acc[t][6]);
-                    acc[t][7] = fma_mix_hi(v.w, wk[kx][7], acc[t][7]);
+                    const bool first = ky == 0 && kx == 0;   // the accumulator's first tap takes the bias as its addend
+                    acc[t][0] = fma_mix_lo(v.x, wk[kx][0], first ? bs[0] : acc[t][0]);
+                    acc[t][1] = fma_mix_hi(v.x, wk[kx][1], first ? bs[1] : acc[t][1]);
+                    acc[t][2] = fma_mix_lo(v.y, wk[kx][2], first ? bs[2] : acc[t][2]);
+                    acc[t][3] = fma_mix_hi(v.y, wk[kx][3], first ? bs[3] : acc[t][3]);
+                    acc[t][4] = fma_mix_lo(v.z, wk[kx][4], first ? bs[4] : acc[t][4]);
+                    acc[t][5] = fma_mix_hi(v.z, wk[kx][5], first ? bs[5] : acc[t][5]);
+                    acc[t][6] = fma_mix_lo(v.w, wk[kx][6], first ? bs[6] : acc[t][6]);
+                    acc[t][7] = fma_mix_hi(v.w, wk[kx][7], first ? bs[7] : acc[t][7]);
                 }
             }
         }
