@@ -403,13 +403,33 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
     }
 }
 
+static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
+{
+    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
+    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
+    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
+    uint4 d;
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
+          "v"(g1[2]), "v"(g1[3]));
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // thin_proj_kernel: SE-scale + project conv (+ skip) for layers with K <= 64 and N <= 32 on big images (B4's expand-less
 // blocks 0 and 1: 48 -> 24 and 24 -> 24 at 112x112).  pw_gemm_kernel gives such a layer one k-step of work per workgroup
 // between two barriers (0.6-1.1 TB/s measured); here a workgroup owns a run of one patch's pixel fragments, keeps the
 // 2*KSTEPS weight fragments and the patch's gate in registers, and each wave streams fragments with the next one's loads in
-// flight.  Same weight packing (pack_pw, nt = 2) and the same arithmetic order as pw_gemm_kernel<.,2,EPI_LINEAR,GATE,RES>:
-// results are bitwise identical.
+// flight.  Same weight packing (pack_pw, nt = 2) as pw_gemm_kernel<.,2,EPI_LINEAR,GATE,RES>.
 // ---------------------------------------------------------------------------------------------
 template <int KSTEPS, bool RES>
 __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restrict__ X, int K, const _Float16* __restrict__ Wp,
@@ -423,17 +443,24 @@ __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restri
     const int nfrag = HW >> 4;   // HW is a multiple of 16
     const int f0 = blockIdx.x * frags_per_wg;
     const int f1 = f0 + frags_per_wg < nfrag ? f0 + frags_per_wg : nfrag;
+    // The squeeze-excite gate goes into the WEIGHT fragments, once per workgroup (the A operand's k index of lane quarter q is
+    // 8q .. 8q+7: the patch's gate values for those input channels): no gate registers (2 x 4 per k-step) and no per-fragment
+    // scaling of the activations (8 conversions + products per k-step and fragment) -- what kept five-k-step layers (block 2's
+    // project) slower here than on pw_gemm_kernel.  w * g rounded to fp16 instead of x * g: the same size of rounding error.
     h8 wf[KSTEPS][2];
-    f4 g0[KSTEPS], g1[KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wf[ks][t] = *reinterpret_cast<const h8*>(Wp + ((size_t)(ks * 2 + t) * 64 + lane) * 8);
         const int k = ks * 32 + q * 8;
-        g0[ks] = g1[ks] = (f4){0.f, 0.f, 0.f, 0.f};
+        f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
         if (k < K) {
-            g0[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k);
-            g1[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k + 4);
+            g0 = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k);
+            g1 = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint4 w = *reinterpret_cast<const uint4*>(Wp + ((size_t)(ks * 2 + t) * 64 + lane) * 8);
+            const uint4 gw = gate_h8(w, g0, g1);
+            wf[ks][t] = *reinterpret_cast<const h8*>(&gw);
         }
     }
     const int cbase = q * 8;   // lane (m,q) owns channels 8q .. 8q+7 (4t + j) of pixel row m of the fragment
@@ -463,14 +490,8 @@ __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restri
         f4 a0 = bv0, a1 = bv1;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            h8 v = xc[ks];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = (_Float16)((float)v[j] * g0[ks][j]);
-                v[4 + j] = (_Float16)((float)v[4 + j] * g1[ks][j]);
-            }
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][0], v, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][1], v, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][0], xc[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][1], xc[ks], a1, 0, 0, 0);
         }
         if (cbase < N) {   // N is a multiple of 8 here
             h8 o;
@@ -1111,26 +1132,6 @@ static __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float a
     return d;
 }
 
-static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
-{
-    // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
-    // v_fma_mixlo/hi_f16 read the fp16 half directly and write one half of the destination.  The result is an MFMA
-    // operand: the VALU-write -> MFMA-read wait states are not padded by the compiler inside asm, hence the s_nop.
-    uint4 d;
-    asm("v_fma_mixlo_f16 %0, %4, %8, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %4, %9, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %1, %5, %10, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %1, %5, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %2, %6, %12, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %2, %6, %13, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixlo_f16 %3, %7, %14, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %3, %7, %15, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "s_nop 1"
-        : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
-        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w), "v"(g0[0]), "v"(g0[1]), "v"(g0[2]), "v"(g0[3]), "v"(g1[0]), "v"(g1[1]),
-          "v"(g1[2]), "v"(g1[3]));
-    return d;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused MBConv front half: expand 1x1 (+bias+SiLU) -> LDS -> depthwise KSxKS stride ST (+bias+SiLU)

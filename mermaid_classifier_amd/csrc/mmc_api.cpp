@@ -1018,7 +1018,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
         // small-K, small-N project on a big image: thin_proj_kernel (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
-        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 3; }();
+        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 5; }();
         const bool use_thin = bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && B.project.Kp / 32 <= thin_max && B.project.N <= 32 &&
                               (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136;
         // block 1's depthwise output as three 32-channel planes between mb1_kernel and thin_proj_kernel (see mb1_kernel); per-tensor
