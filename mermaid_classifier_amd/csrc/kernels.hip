@@ -3302,7 +3302,13 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
     // ---------------- expand ----------------
     {
         u4v xr[4][CKS];
-        bool okp[4][2];   // validity of this lane's two output pairs (positions 16 pf + 4q .. +3): window and image
+        // validity of this lane's two output pairs (positions 16 pf + 4q .. +3): window and image.  The window's columns always lie
+        // inside the image (wx0 .. wx0 + WW - 1 <= HIMG - 1), only its first R / last R rows can fall outside (top / bottom tiles).
+        // 3x3: those rows are NOT zeroed in E -- the one tap that reads them (kernel row 0 of output row 0 at the top, kernel row 2
+        // of output row 13 at the bottom) gets zero weights in the depthwise threads that own those rows: 8 selects per thread instead
+        // of 6 per stored fragment plus the bookkeeping of which pairs lie outside.  5x5 has six such (row, kernel row) pairs: it keeps E zeroed.
+        constexpr bool MASK_E = KSD != 3;
+        bool okp[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = 16 * (wave + 8 * i) + m;
@@ -3315,7 +3321,7 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                 const int pp = 16 * (wave + 8 * i) + 4 * q + 2 * h;      // even: the pair lies in one window row, and is in or out
                 const int pr = pp / WW, pc = pp - pr * WW;               // of the image as a whole (wx0 and HIMG are even)
                 const int py = oy0 - R + pr;
-                okp[i][h] = pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG;
+                okp[i][h] = !MASK_E || (pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG);
             }
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
@@ -3416,6 +3422,13 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
                     } else {
                         wq[0][0] = r0 << 16; wq[0][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[0][2] = 0u;
                         wq[1][0] = r0; wq[1][1] = r1; wq[1][2] = 0u;
+                        // window row ro + ky of this band lies outside the image: top tile, output row 0, kernel row 0; bottom tile,
+                        // output row 13 (band 4, ro = 1), kernel row 2
+                        if ((ro == 0 && ky == 0) || (ro == 1 && ky == 2)) {
+                            const bool out = ro == 0 ? (oy0 + rb == 0) : (oy0 + rb + 1 == HIMG - 1);
+                            wq[0][0] = out ? 0u : wq[0][0]; wq[0][1] = out ? 0u : wq[0][1];
+                            wq[1][0] = out ? 0u : wq[1][0]; wq[1][1] = out ? 0u : wq[1][1];
+                        }
                     }
 #pragma unroll
                     for (int ip = 0; ip < NP; ++ip)
@@ -3485,6 +3498,11 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
     // ---------------- expand ----------------
     {
         u4v xr[NS][CKS];
+        // 3x3 (28 -> 14, TF-same pads bottom / right only): image row 28 and columns 28, 29 of the window are NOT zeroed in E -- the
+        // taps that read them (kernel row 2 of output row 13; kernel column 2 of output column 13, always the tile's last) get a zero
+        // weight / are left out in the depthwise phase.  5x5 (pads on all four sides) keeps E zeroed.
+        constexpr bool MASK_E = KSD != 3;
+        static_assert(KSD != 3 || HIMG == 28, "the 3x3 stride-2 shortcut assumes one tile column");
         bool okp[NS][2];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -3498,7 +3516,7 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
                 const int pp = 16 * (wave + 8 * i) + 4 * q + 2 * h;
                 const int pr = pp / WW, pc = pp - pr * WW;
                 const int py = wy0 + pr;
-                okp[i][h] = pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG;
+                okp[i][h] = !MASK_E || (pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG);
             }
 #pragma unroll
             for (int ks = 0; ks < CKS; ++ks) {
@@ -3583,11 +3601,18 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
             const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
             uint32_t wq[3];
             if (KSD == 5) { wq[0] = r0 << 16; wq[1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[2] = __builtin_amdgcn_alignbit(r2, r1, 16); }
-            else { wq[0] = r0; wq[1] = r1; wq[2] = 0u; }
+            else {
+                wq[0] = r0; wq[1] = r1; wq[2] = 0u;
+                if (ky == 2) {   // window row 2 orow + 2 is image row 28 for output row 13
+                    const bool out = oy0 + orow == HOUT - 1;
+                    wq[0] = out ? 0u : wq[0]; wq[1] = out ? 0u : wq[1];
+                }
+            }
 #pragma unroll
             for (int ip = 0; ip < NIP; ++ip)
 #pragma unroll
                 for (int j = 0; j < 14; ++j) {
+                    if (KSD == 3 && j == 13 && ip == 1) continue;   // (k2, 0) on columns 28, 29: outside the image
                     if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ip], dbias);
                     else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ip]), acc[j], false);
                 }
