@@ -3885,8 +3885,10 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     unsigned char* wl = smem;                                           // [NF][KS][64 lanes][16 B]
     float* pooled = reinterpret_cast<float*>(smem + NF * KS * 1024);    // [KP]
     float* gate = pooled + KP;                                          // [KP]
-    float* part = reinterpret_cast<float*>(smem);                       // [64][32] FC1 partials: alias wl (written later)
-    float* rs = part + 64 * 32;                                         // [32]
+    float* rs = gate + KP;                                              // [32] squeeze activations
+    float* part = rs + 32;                                              // [64][28] FC1 partials (outside wl: the weights stream into
+                                                                        // LDS by DMA while the reduce reads them)
+    constexpr int PST = 28;                                             // row stride of part (CSP <= 28)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
@@ -3902,9 +3904,14 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     //      ISSUED its loads (the memory pipe takes 64 B/clk), so: chain inputs first (pool partials, then the FC
     //      weights), all unpredicated and straight-line; the bulk loads go out after the first barrier and stream
     //      in while the FCs compute.
+    // Pool channels: thread t takes channel t and channel t + 512 -- except wave 7 (it issues the weight DMA below and would get its
+    // sums back only behind it): its channels 448 .. 511 ride in the second slot of threads 160 .. 223, which is free (K <= 672).
+    static_assert(KP <= 672, "channel 448..511 reassignment assumes no channel t + 512 for t >= 160");
     float ps0 = 0.f, ps1 = 0.f;
+    const int pk0 = tid, pk1 = (tid >= 160 && tid < 224) ? tid + 288 : tid + 512;
+    const bool pw = wave != 7;
     {
-        const int k0 = tid < K ? tid : 0, k1 = tid + 512 < K ? tid + 512 : 0;
+        const int k0 = (pw && pk0 < K) ? pk0 : 0, k1 = (pw && pk1 < K) ? pk1 : 0;
         if (a.nparts == 1) {
             ps0 = gload<float>(pp, (unsigned)((b * K + k0) * 4));
             ps1 = gload<float>(pp, (unsigned)((b * K + k1) * 4));
@@ -3941,7 +3948,8 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 #pragma unroll
     for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
     const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
-    const float brv = tid < CSP ? a.br[tid] : 0.f;
+    const int rt = tid - 448;   // the reduce runs in wave 7 (threads 448 .. 448 + CSP - 1)
+    const float brv = (rt >= 0 && rt < CSP) ? a.br[rt] : 0.f;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
     auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
 #pragma unroll
@@ -3961,16 +3969,34 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
             }
         }
     };
-    if (tid < KP) pooled[tid] = tid < K ? ps0 : 0.f;
-    if (tid + 512 < KP) pooled[tid + 512] = tid + 512 < K ? ps1 : 0.f;
+    // Bulk loads, behind the chain's inputs in every wave's queue.  The project weights (<= 147 KB, the same for every workgroup) go
+    // from L2 STRAIGHT into LDS (global_load_lds_dwordx4: wave-uniform LDS base + lane x 16 bytes = the lane-linear fragment image),
+    // ALL of them issued by wave 7, which has no part in FC1: no 76 staging registers, no ds_write pass, and no other wave has a DMA
+    // in flight (hipcc waits for vmcnt(0) at the next use of a plain load while one is).  Staged through registers by all waves
+    // between FC1 and the reduce, the requests' issue alone (264 KB per workgroup at ~32 B/clk) put 8 k cycles between those two
+    // barriers, and parking the weights cost another 2 k behind FC2.  The first pixel fragments are requested here as well.
+    // (A wave issues in order and the memory pipe pushes back: with every wave's first pixel fragments up here too -- 264 KB per
+    // workgroup in front of the chain -- the pooled barrier came at 15 k cycles.  They go out behind FC1, in the waves that idle there.)
+    // A CU's memory pipe serves requests in issue order, whichever wave they come from: the barrier puts every wave's chain inputs in
+    // the queue ahead of the first DMA piece (without it the pool sums came back behind the weights: pooled barrier at 11 k cycles).
+    h8 xc[2][CK], xn[2][CK];
+    PIN_VMEM();
+    __builtin_amdgcn_s_barrier();
+    if (wave == 7) {
+#pragma unroll 7
+        for (int i = 0; i < NF * KS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wfrag + ((size_t)i * 64 + lane) * 8),
+                                             (__attribute__((address_space(3))) void*)(wl + i * 1024), 16, 0, 0);
+        PIN_VMEM();
+    }
+    if (pw && pk0 < KP) pooled[pk0] = pk0 < K ? ps0 : 0.f;
+    if (pw && pk1 < KP) pooled[pk1] = pk1 < K ? ps1 : 0.f;
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 3] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC1: r = silu(br + psc * pooled . Wr^T) ----
     // (The bulk loads -- 147 KB of project weights and the first pixel fragments, 33 x 16 bytes per thread -- used to be issued
     // HERE, in front of FC1: their address processing alone takes ~4 k cycles per workgroup and FC1's barrier came 9-10 k cycles
     // after the pooled one.  They are needed only after FC2, so they now go out behind FC1 and stream in under the reduce and FC2.)
-    h8 xc[2][CK], xn[2][CK];
-    h8 wreg[WPT];
     if (fc1_thr) {
         f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -3982,30 +4008,26 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
             acc[2] = fma_mix_lo(w1[i].y, x, acc[2]);
             acc[3] = fma_mix_hi(w1[i].y, x, acc[3]);
         }
-        *reinterpret_cast<f4*>(part + sl * 32 + 4 * j4) = acc;
+        *reinterpret_cast<f4*>(part + sl * PST + 4 * j4) = acc;
     }
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
-    // bulk loads: project weights (registers now, parked in LDS after FC2), first pixel fragments of this wave
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int c = tid + 512 * i;
-        wreg[i] = gload<h8>(wfrag, (unsigned)((c < NWCH ? c : 0) * 16));
-    }
-    if (wave < NPAIR) load_chunk(wave, 0, xc);
-    PIN_VMEM();
-    if (tid < CSP) {
+    // first pixel fragments of every wave (wave 7's behind its reduce)
+    if (wave != 7 && wave < NPAIR) { load_chunk(wave, 0, xc); PIN_VMEM(); }
+    // wave 7 (idle during FC1) reduces FC1's partials
+    if (wave == 7 && rt < CSP) {
         float s = 0.f;   // 16 partials per round of LDS reads (one latency per 16, not per partial), summed in the fixed order
 #pragma unroll
         for (int w0 = 0; w0 < 64; w0 += 16) {
             float pv[16];
 #pragma unroll
-            for (int w = 0; w < 16; ++w) pv[w] = part[(w0 + w) * 32 + tid];
+            for (int w = 0; w < 16; ++w) pv[w] = part[(w0 + w) * PST + rt];
 #pragma unroll
             for (int w = 0; w < 16; ++w) s += pv[w];
         }
-        rs[tid] = silu_f(s * a.psc + brv);
+        rs[rt] = silu_f(s * a.psc + brv);
     }
+    if (wave == 7 && wave < NPAIR) { load_chunk(wave, 0, xc); PIN_VMEM(); }
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 5] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC2: gate = sigmoid(be + r . We^T) ----
@@ -4027,13 +4049,8 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
             }
         }
     }
-    T7_BAR();
-    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 6] = (float)((long long)__builtin_readcyclecounter() - tk0);          // FC1 partials (aliasing wl) are dead from here
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int c = tid + 512 * i;
-        if (c < NWCH) *reinterpret_cast<h8*>(wl + c * 16) = wreg[i];
-    }
+    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 6] = (float)((long long)__builtin_readcyclecounter() - tk0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // wave 7: the DMA has landed
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 7] = (float)((long long)__builtin_readcyclecounter() - tk0);
     if (a.dbg_clk) tk1 = (long long)__builtin_readcyclecounter();
@@ -4748,7 +4765,7 @@ int proj_patch_ksteps(int K)
 template <int KS, int NF, int HW, bool RES>
 static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 {
-    const int lds = NF * KS * 1024 + 2 * 32 * KS * 4;
+    const int lds = NF * KS * 1024 + 2 * 32 * KS * 4 + 128 + 64 * 28 * 4;   // project weights, pooled + gate vectors, squeeze activations, FC1 partials
     if (NF * KS * 1024 < (64 * 32 + 32) * 4) return -10;   // FC1 scratch aliases the weight image
     static bool attr_done = false;
     if (!attr_done) {
