@@ -3873,7 +3873,10 @@ __global__ __launch_bounds__(512, 4) void mb3_kernel(Mb3Args a)
 template <int KS, int NF, int HW, bool RES>
 __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 {
-    constexpr int CK = (KS <= 8) ? KS : (KS % 7 == 0 ? 7 : (KS % 5 == 0 ? 5 : 6));   // k-steps per chunk (KS = 21 -> 7, 15 -> 5, 12 -> 6)
+    // k-steps per chunk of pixel fragments (the next chunk is in flight while one computes).  Small chunks put fewer bytes in front
+    // of the first MFMA (the prologue is bound by them): KS = 21 -> 3 (22.2 -> 21.4 us), KS = 15 -> 3 with five output fragments
+    // (16.0 -> 15.5 us) but 5 with seven (3: 16.6 -> 17.2 us), KS = 12 -> 6.
+    constexpr int CK = (KS <= 8) ? KS : (KS % 7 == 0 ? 3 : (KS % 5 == 0 ? (NF <= 5 ? 3 : 5) : 6));
     constexpr int NCH = KS / CK;
     static_assert(KS % CK == 0, "chunking");
     constexpr int NPF = (HW + 15) / 16, NPAIR = (NPF + 1) / 2;
