@@ -3136,15 +3136,17 @@ __global__ __launch_bounds__(512, 4) void mb1_kernel(Mb1Args a)   // 128 VGPRs: 
             const bool ok = pf < NPF && p < NPOS && iy < 112 && ix < 112;
             xr[i] = gload<u4v>(xg, (unsigned)((((ok ? iy : 0) * 112 + (ok ? ix : 0)) * 32 + 8 * q) * 2));
         }
-        const h8 wpre = *reinterpret_cast<const h8*>(a.pre_w + lane * 8);
+        // block 0's squeeze-excite gate goes into the project's weight fragment (lane quarter q holds input channels 8q .. 8q+7 of
+        // both operands), once per tile, instead of into every pixel fragment (8 conversions + products each)
+        const uint4 wraw = *reinterpret_cast<const uint4*>(a.pre_w + lane * 8);
         const f4 bpre = *reinterpret_cast<const f4*>(a.pre_b + 4 * q);
         const f4 g0 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q);
         const f4 g1 = *reinterpret_cast<const f4*>(a.pre_gate + (size_t)b * 32 + 8 * q + 4);
+        const uint4 wgated = gate_h8(wraw, g0, g1);
+        const h8 wpre = *reinterpret_cast<const h8*>(&wgated);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint4 xin = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
-            const uint4 gx = gate_h8(xin, g0, g1);
-            const f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&gx), bpre, 0, 0, 0);
+            const f4 x1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpre, *reinterpret_cast<const h8*>(&xr[i]), bpre, 0, 0, 0);
             h4 xh;
 #pragma unroll
             for (int j = 0; j < 4; ++j) xh[j] = (_Float16)x1[j];
