@@ -3481,7 +3481,7 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
     constexpr int HOUT = HIMG / 2, TX = HOUT / 14, NPR = KSD == 5 ? 16 : 15;   // pixel pairs per window row a thread needs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* E = smem;                                            // [NS*8*8][ES2]
-    float* pred = reinterpret_cast<float*>(smem + NS * 64 * ES2);       // [7][48]
+    float* pred = reinterpret_cast<float*>(smem + NS * 64 * ES2);       // [14][48]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
@@ -3575,33 +3575,42 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
     }
     T7_BAR();
     // ---------------- depthwise, stride 2 ----------------
-    // 7 output rows x 48 channels = 336 threads: waves 6 and 7 have nothing to do and skip the phase (their copy of the work used
-    // to cost the vector port a quarter of it); the lanes of wave 5 past thread 335 repeat row 6 (same values, same addresses),
-    // so no store sits behind a branch
-    if (wave < 6) {
-        const int c = tid % CH, orow = tid < 7 * CH ? tid / CH : 6;
+    // Work item = (channel, output row, half of the 14 columns): 672 items of 7 outputs over 512 threads -- a first pass of all eight
+    // waves, a second of waves 0 .. 2 (a few threads repeat an item: same values, same addresses, no branch around a store).
+    // One item per (channel, output row) was 336 threads: waves 0 .. 5 carried 14 outputs each while 6 and 7 idled -- two SIMDs with
+    // two loaded waves, two with one; now the busiest SIMD issues three half-items' worth instead of four, and the window is 9 pairs
+    // per row instead of 16.
+    constexpr int NPH = KSD == 5 ? 9 : 8;   // window pairs of a half row: output 7 half + j reads the pairs 7 half + j + ip
+    static_assert(KSD == 5 ? (7 + NPH - 1 < WW / 2 + 1) : (7 + NPH - 1 < WW / 2), "the last pair of the right half lies inside the window");
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && wave >= 3) break;   // wave-uniform: items 512 .. 671 are waves 0 .. 2
+        // A thread keeps its channel (tid % 48: its taps are in registers): pass 0 takes rows 0 .. 10 of the 14 (row 10: channels
+        // 0 .. 31), pass 1 rows 11, 12, 13 in threads 0 .. 143 and the rest of row 10 in threads 144 .. 191 (whose channels 0 .. 31
+        // repeat pass 0's items).
+        const int c = tid % CH, r1 = tid / CH;
+        const int rest = pass == 0 ? r1 : (r1 < 3 ? 11 + r1 : 10);        // rest = 7 half + output row
+        const int half = rest >= 7 ? 1 : 0, orow = rest - 7 * half;
         const int cg = chunk * CH + c;
-        // only window pair l = 0 (left image border: pbase = -1) can fall outside the window on the left, only the last one on
-        // the right; the whole pair is zero padding then
-        const bool lok = pbase >= 0, rok = pbase + NPR - 1 < WW / 2;
-        const unsigned char* col = E + 4 * c + (lok ? pbase : 0) * ES2;
+        // only window pair 0 of the left half can fall outside the window (left image border: pbase = -1): zero padding
+        const int pb = pbase + 7 * half;
+        const bool lok = pb >= 0;
+        const unsigned char* col = E + 4 * c + (lok ? pb : 0) * ES2;
         const int o0 = lok ? 0 : -ES2;
-        uint32_t P[KSD][NPR];
+        uint32_t P[KSD][NPH];
 #pragma unroll
         for (int ky = 0; ky < KSD; ++ky) {
             const unsigned char* rowp = col + ((2 * orow + ky) * (WW / 2)) * ES2;
             const uint32_t v0 = *reinterpret_cast<const uint32_t*>(rowp);
             P[ky][0] = lok ? v0 : 0u;
 #pragma unroll
-            for (int l = 1; l < NPR - 1; ++l) P[ky][l] = *reinterpret_cast<const uint32_t*>(rowp + o0 + l * ES2);
-            const uint32_t vl = *reinterpret_cast<const uint32_t*>(rowp + o0 + (rok ? NPR - 1 : NPR - 2) * ES2);
-            P[ky][NPR - 1] = rok ? vl : 0u;
+            for (int l = 1; l < NPH; ++l) P[ky][l] = *reinterpret_cast<const uint32_t*>(rowp + o0 + l * ES2);
         }
-        float acc[14];
+        float acc[7];
 #pragma unroll
         for (int ky = 0; ky < KSD; ++ky) {
             const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
-            uint32_t wq[3];
+            uint32_t wq[3], wql = 0u;
             if (KSD == 5) { wq[0] = r0 << 16; wq[1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[2] = __builtin_amdgcn_alignbit(r2, r1, 16); }
             else {
                 wq[0] = r0; wq[1] = r1; wq[2] = 0u;
@@ -3609,34 +3618,36 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
                     const bool out = oy0 + orow == HOUT - 1;
                     wq[0] = out ? 0u : wq[0]; wq[1] = out ? 0u : wq[1];
                 }
+                wql = half ? 0u : wq[1];   // (k2, 0) of output column 13 falls on columns 28, 29: outside the image
             }
 #pragma unroll
             for (int ip = 0; ip < NIP; ++ip)
 #pragma unroll
-                for (int j = 0; j < 14; ++j) {
-                    if (KSD == 3 && j == 13 && ip == 1) continue;   // (k2, 0) on columns 28, 29: outside the image
-                    if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ip], dbias);
-                    else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ip]), acc[j], false);
+                for (int j = 0; j < 7; ++j) {
+                    const uint32_t wt = (KSD == 3 && j == 6 && ip == 1) ? wql : wq[ip];
+                    if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wt, dbias);
+                    else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wt), acc[j], false);
                 }
         }
         f2 psum2 = {0.f, 0.f};
-        uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * HOUT + oy0 + orow) * HOUT + ox0) * CE + cg);
+        uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * HOUT + oy0 + orow) * HOUT + ox0 + 7 * half) * CE + cg);
         silu_scaled_staged(acc);
 #pragma unroll
-        for (int j = 0; j < 14; j += 2) {
+        for (int j = 0; j < 6; j += 2) {
             const f2 v = {acc[j], acc[j + 1]};
             psum2 = psum2 + v;
             const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);
             dg[(size_t)j * CE] = (uint16_t)hv;
             dg[(size_t)(j + 1) * CE] = (uint16_t)(hv >> 16);
         }
-        pred[orow * CH + c] = psum2.x + psum2.y;
+        reinterpret_cast<_Float16*>(dg)[(size_t)6 * CE] = (_Float16)acc[6];
+        pred[rest * CH + c] = (psum2.x + psum2.y) + acc[6];
     }
     T7_BAR();
     if (tid < CH) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 7; ++w) s += pred[w * CH + tid];
+        for (int w = 0; w < 14; ++w) s += pred[w * CH + tid];
         a.pool[((size_t)b * gridDim.x + tile) * CE + chunk * CH + tid] = s;
     }
 }
@@ -4910,7 +4921,7 @@ template <int KSD, int CKS, int CE, int HIMG>
 static int launch_mbt2_t(const MbtArgs& a, hipStream_t st)
 {
     constexpr int NROWS = 12 + KSD, WW = KSD == 5 ? 32 : 30, NPF = (NROWS * WW + 15) / 16, NS = (NPF + 7) / 8, HOUT = HIMG / 2;
-    const int lds = NS * 64 * 224 + 7 * 48 * 4;
+    const int lds = NS * 64 * 224 + 14 * 48 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbt2_kernel<KSD, CKS, CE, HIMG>),
