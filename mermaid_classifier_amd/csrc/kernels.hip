@@ -1868,7 +1868,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             // window reaches outside: read as zeros instead of being selected to zero register by register); 131.4 KB in all, X's
             // region (unused until block 11's project) included
             unsigned char* EB = ED + T7_PIX * T7_DS11 + 7 * ES2;
-            float* pband = part;                               // [4][96] pool partials of the row bands
+            float* pband = part;                               // [7][96] pool partials of the output rows
             const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.pre_wexp);
             const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.pre_bexp);
             const GLOBAL_AS uint32_t* dwp = sgpr_ptr<uint32_t>(a.pre_dwp);
@@ -1896,7 +1896,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 const int row = e / (ES2 / 16), c16 = e - row * (ES2 / 16);
                 *reinterpret_cast<uint4*>(EB + (row < 7 ? row - 7 : row + 91) * ES2 + 16 * c16) = uint4{0u, 0u, 0u, 0u};
             }
-            const int band = tid / CH, cd = tid - band * CH;   // waves 6 and 7 (band >= 4) sit the depthwise phase out
+            const int band = tid / CH, cd = tid - band * CH;   // depthwise role: channel cd, output row(s) by tid / 96 (see the depthwise phase)
             // Weight fragments AND the bias of the next output fragment are requested one fragment ahead (across the chunk
             // boundary too; fragment 42 = fragment 41 re-read, unused), bias first: a load needed now is never queued behind
             // loads needed later (vmcnt retires in order).  The wave's role (two pixel fragments or one) is a template argument
@@ -1906,7 +1906,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             float bsn = gload<float>(bexp, (unsigned)m * 4u);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) wn[ks] = gload<h8>(wexp, (unsigned)((ks * 64 + lane) * 16));
-            unsigned char* const scratch = reinterpret_cast<unsigned char*>(part) + 2048 + lane * 4;   // beyond pband, unread
+            unsigned char* const scratch = reinterpret_cast<unsigned char*>(part) + 3072 + lane * 4;   // beyond pband ([7][96] floats), unread
             auto expand_chunk = [&](auto npf_tag, int chunk) {
                 constexpr int NPF = decltype(npf_tag)::value;
 #pragma unroll
@@ -1959,54 +1959,55 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 if (npf == 2) expand_chunk(std::integral_constant<int, 2>{}, chunk);
                 else expand_chunk(std::integral_constant<int, 1>{}, chunk);
                 T7_BAR();
-                if (wave < 6) {   // 4 bands x 96 channels = waves 0..5 exactly
-                    const unsigned char* col = EB + 4 * cd + ((4 * band - 1) * 7) * ES2;   // (band 0 starts in the zero row)
-                    uint32_t P[7][7];
+                // Work item = (channel, output row): 7 x 96 = 672 items of 7 outputs over 512 threads, a thread keeping its channel
+                // (tid % 96: its taps are in registers) -- pass 0: rows 0 .. 5 (row 5: channels 0 .. 31), pass 1 (waves 0 .. 2): row 6
+                // in threads 0 .. 95, the rest of row 5 in threads 96 .. 191 (channels 0 .. 31 repeat pass 0's items: same values, same
+                // addresses).  With bands of two rows in waves 0 .. 5, two SIMDs carried two loaded waves and two carried one.
+#pragma unroll 1
+                for (int pass = 0; pass < 2; ++pass) {
+                    if (pass == 1 && wave >= 3) break;   // wave-uniform
+                    const int oy = pass == 0 ? band : (band == 0 ? 6 : 5);
+                    const unsigned char* col = EB + 4 * cd + ((2 * oy - 1) * 7) * ES2;   // (row 0 starts in the zero row above the image)
+                    uint32_t P[5][7];
 #pragma unroll
-                    for (int r = 0; r < 7; ++r)
+                    for (int r = 0; r < 5; ++r)
 #pragma unroll
                         for (int pp = 0; pp < 7; ++pp) P[r][pp] = *reinterpret_cast<const uint32_t*>(col + (r * 7 + pp) * ES2);
-                    f2 psum2 = {0.f, 0.f};
-                    float psum1 = 0.f;
                     unsigned char* dcol = ED + (chunk * CH + cd) * 2;
+                    float acc[7];
+                    bool started[7] = {false, false, false, false, false, false, false};
 #pragma unroll
-                    for (int ro = 0; ro < 2; ++ro) {
-                        const int oy = 2 * band + ro;
-                        if (oy < 7) {
-                            float acc[7];
-                            bool started[7] = {false, false, false, false, false, false, false};
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
+                        const uint32_t wq[3] = {r0 << 16, __builtin_amdgcn_alignbit(r1, r0, 16), __builtin_amdgcn_alignbit(r2, r1, 16)};
 #pragma unroll
-                            for (int ky = 0; ky < 5; ++ky) {
-                                const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
-                                const uint32_t wq[3] = {r0 << 16, __builtin_amdgcn_alignbit(r1, r0, 16), __builtin_amdgcn_alignbit(r2, r1, 16)};
+                        for (int ip = 0; ip < 3; ++ip)
 #pragma unroll
-                                for (int ip = 0; ip < 3; ++ip)
-#pragma unroll
-                                    for (int ox = 0; ox < 7; ++ox) {
-                                        const int xpc = ox - 1 + ip;
-                                        if (xpc < 0 || xpc > 6) continue;
-                                        if (!started[ox]) { acc[ox] = dot2_from(P[2 * ro + ky][xpc], wq[ip], dbias); started[ox] = true; }
-                                        else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[2 * ro + ky][xpc]),
-                                                                              *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
-                                    }
+                            for (int ox = 0; ox < 7; ++ox) {
+                                const int xpc = ox - 1 + ip;
+                                if (xpc < 0 || xpc > 6) continue;
+                                if (!started[ox]) { acc[ox] = dot2_from(P[ky][xpc], wq[ip], dbias); started[ox] = true; }
+                                else acc[ox] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][xpc]),
+                                                                      *reinterpret_cast<const h2*>(&wq[ip]), acc[ox], false);
                             }
-                            silu_scaled_staged(acc);
-#pragma unroll
-                            for (int ox = 0; ox < 6; ox += 2) {
-                                const f2 v = {acc[ox], acc[ox + 1]};
-                                psum2 = psum2 + v;
-                                const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
-                                *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox) * T7_DS11) = (uint16_t)hv;
-                                *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox + 1) * T7_DS11) = (uint16_t)(hv >> 16);
-                            }
-                            psum1 += acc[6];
-                            *reinterpret_cast<_Float16*>(dcol + (oy * 7 + 6) * T7_DS11) = (_Float16)acc[6];
-                        }
                     }
-                    pband[band * CH + cd] = (psum2.x + psum2.y) + psum1;
+                    silu_scaled_staged(acc);
+                    f2 psum2 = {0.f, 0.f};
+#pragma unroll
+                    for (int ox = 0; ox < 6; ox += 2) {
+                        const f2 v = {acc[ox], acc[ox + 1]};
+                        psum2 = psum2 + v;
+                        const uint32_t hv = cvt_pk_f16(acc[ox], acc[ox + 1]);
+                        *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox) * T7_DS11) = (uint16_t)hv;
+                        *reinterpret_cast<uint16_t*>(dcol + (oy * 7 + ox + 1) * T7_DS11) = (uint16_t)(hv >> 16);
+                    }
+                    *reinterpret_cast<_Float16*>(dcol + (oy * 7 + 6) * T7_DS11) = (_Float16)acc[6];
+                    pband[oy * CH + cd] = (psum2.x + psum2.y) + acc[6];
                 }
                 T7_BAR();
-                if (tid < CH) pooled[chunk * CH + tid] = ((pband[tid] + pband[CH + tid]) + pband[2 * CH + tid]) + pband[3 * CH + tid];
+                if (tid < CH)
+                    pooled[chunk * CH + tid] = (((pband[tid] + pband[CH + tid]) + (pband[2 * CH + tid] + pband[3 * CH + tid])) +
+                                                (pband[4 * CH + tid] + pband[5 * CH + tid])) + pband[6 * CH + tid];
             }
             if (a.dbg_dw) {   // per-tensor mode: block 11's depthwise output as the separate kernels would have stored it
                 T7_BAR();
