@@ -59,9 +59,10 @@ struct TailBlock {
     const float* bexp;      // [1152]
     const uint32_t* dwp;    // [15][1152] depthwise taps as fp16 pairs: slot 3*ky + d; 5x5: (k0,k1),(k2,k3),(k4,0); 3x3: (k0,k1),(k2,0),0
     const float* bdw;       // [1152]
-    const _Float16* wr_t;   // [1152][48] squeeze FC, channel-major (unscaled: 1/(49*log2e) is applied in fp32)
+    const _Float16* wr_t;   // [18][384][8] squeeze FC: request p of thread (cr, j4) = Wr^T[64p + cr][4 j4 .. +3], Wr^T[64p + 32 + cr][4 j4 .. +3]
+                            // (Wr^T = [1152][48], channel-major; unscaled: 1/(49*log2e) is applied in fp32)
     const float* br;        // [48]
-    const _Float16* we_t;   // [48][1152] excite FC, k-major
+    const _Float16* we_t;   // [24][288][8] excite FC: request p of thread t = We^T[2p][4t .. +3], We^T[2p + 1][4t .. +3] (We^T = [48][1152])
     const float* be;        // [1152]
     const _Float16* wproj;  // [cout/16][36][64][8] project weights, MFMA fragment order
     const float* bproj;     // [cout]

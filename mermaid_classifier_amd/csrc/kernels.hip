@@ -2262,8 +2262,12 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // on the pairs from x-1.  The odd/even variants are derived from the raw row pairs by shifts.
         const bool fc1_thr = tid < 384;
         const int cr = tid / 12, j4 = tid - cr * 12;   // FC1: thread = 4 outputs j x channels cr, cr+32, ...
-        u2v fw1[36];   // 4 fp16 weights each, consumed by v_fma_mix_f32 without conversion
-        u2v fw2[48];   // excite FC: thread = 4 consecutive channels x all 48 squeeze units
+        // Squeeze-excite weights arrive in 16-byte requests, two rows of the old 8-byte layout per request (the host pairs them:
+        // TailBlock::wr_t / we_t): streamed from L2 by every workgroup, a wave-instruction costs ~16-20 cycles of the CU's memory
+        // path whether it carries 512 bytes or 1 KB (tools/ubench/l2_stream.hip: 32-34 vs 51-55 B/clk), and the depthwise phase
+        // waits on exactly this stream.  Same values in the same order as before.
+        u4v fw1[18];   // 2 x 4 fp16 weights each (channels 64p + cr and 64p + 32 + cr), consumed by v_fma_mix_f32 without conversion
+        u4v fw2[24];   // excite FC: thread = 4 consecutive channels x all 48 squeeze units (two per register quad)
         const bool fc2_thr = tid < 288;
         const int t2 = fc2_thr ? tid : 0;
         float brv = 0.f;
@@ -2362,10 +2366,10 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             {
                 const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)
 #pragma unroll
-                for (int i = 0; i < 36; ++i) fw1[i] = gload<u2v>(W.wr_t, (unsigned)(((32 * i + crl) * 48 + 4 * j4) * 2));
+                for (int i = 0; i < 18; ++i) fw1[i] = gload<u4v>(W.wr_t, (unsigned)((i * 384 + crl * 12 + j4) * 16));
             }
 #pragma unroll
-            for (int k = 0; k < 24; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
+            for (int k = 0; k < 12; ++k) fw2[k] = gload<u4v>(W.we_t, (unsigned)((k * 288 + t2) * 16));
             brv = tid < 48 ? gload<float>(W.br, (unsigned)tid * 4u) : 0.f;
             PIN_VMEM();
             {
@@ -2448,18 +2452,22 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         if (fc1_thr) {
             f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 36; ++i) {
-                const float x = pooled[32 * i + cr];
-                acc[0] = fma_mix_lo(fw1[i].x, x, acc[0]);
-                acc[1] = fma_mix_hi(fw1[i].x, x, acc[1]);
-                acc[2] = fma_mix_lo(fw1[i].y, x, acc[2]);
-                acc[3] = fma_mix_hi(fw1[i].y, x, acc[3]);
+            for (int i = 0; i < 18; ++i) {
+                const float x0 = pooled[64 * i + cr], x1 = pooled[64 * i + 32 + cr];
+                acc[0] = fma_mix_lo(fw1[i].x, x0, acc[0]);
+                acc[1] = fma_mix_hi(fw1[i].x, x0, acc[1]);
+                acc[2] = fma_mix_lo(fw1[i].y, x0, acc[2]);
+                acc[3] = fma_mix_hi(fw1[i].y, x0, acc[3]);
+                acc[0] = fma_mix_lo(fw1[i].z, x1, acc[0]);
+                acc[1] = fma_mix_hi(fw1[i].z, x1, acc[1]);
+                acc[2] = fma_mix_lo(fw1[i].w, x1, acc[2]);
+                acc[3] = fma_mix_hi(fw1[i].w, x1, acc[3]);
             }
             *reinterpret_cast<f4*>(part + cr * 48 + 4 * j4) = acc;
         }
         PIN_VMEM();
 #pragma unroll
-        for (int k = 24; k < 48; ++k) fw2[k] = gload<u2v>(W.we_t, (unsigned)((k * T7_CE + 4 * t2) * 2));
+        for (int k = 12; k < 24; ++k) fw2[k] = gload<u4v>(W.we_t, (unsigned)((k * 288 + t2) * 16));
         const f4 bev = gload<f4>(W.be, (unsigned)t2 * 16u);
         PIN_VMEM();
         T7_BAR();
@@ -2479,12 +2487,16 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         if (fc2_thr) {
             f4 acc = bev;
 #pragma unroll
-            for (int k = 0; k < 48; ++k) {
-                const float r = rs[k];
-                acc[0] = fma_mix_lo(fw2[k].x, r, acc[0]);
-                acc[1] = fma_mix_hi(fw2[k].x, r, acc[1]);
-                acc[2] = fma_mix_lo(fw2[k].y, r, acc[2]);
-                acc[3] = fma_mix_hi(fw2[k].y, r, acc[3]);
+            for (int k = 0; k < 24; ++k) {
+                const float r0 = rs[2 * k], r1 = rs[2 * k + 1];
+                acc[0] = fma_mix_lo(fw2[k].x, r0, acc[0]);
+                acc[1] = fma_mix_hi(fw2[k].x, r0, acc[1]);
+                acc[2] = fma_mix_lo(fw2[k].y, r0, acc[2]);
+                acc[3] = fma_mix_hi(fw2[k].y, r0, acc[3]);
+                acc[0] = fma_mix_lo(fw2[k].z, r1, acc[0]);
+                acc[1] = fma_mix_hi(fw2[k].z, r1, acc[1]);
+                acc[2] = fma_mix_lo(fw2[k].w, r1, acc[2]);
+                acc[3] = fma_mix_hi(fw2[k].w, r1, acc[3]);
             }
             f4 o;
 #pragma unroll

@@ -165,6 +165,7 @@ struct BlockW {
     uint32_t* t_dwp = nullptr;
     _Float16* dw_diag = nullptr;  // mid14m_kernel: block-diagonal depthwise fragments [ce/16][NT][64][8] (depthwise on the matrix pipe)
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
+    _Float16 *t_wr2 = nullptr, *t_we2 = nullptr; // ... blocks 12-15: paired rows for tail7_kernel's 16-byte requests
     // proj_patch_kernel packing (blocks 3..10): project weights/bias padded to whole fragments, SE FCs as above with
     // Cs padded to a multiple of 4
     bool pp = false;
@@ -617,6 +618,21 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_wr, wrt));
                 TRY_OR_FREE(dev_upload(bb, &B.t_we, wet));
+                if (tail_enabled && i >= 12 && i <= 15 && B.cs == 48 && B.ce == 1152) {
+                    // tail7_kernel's 16-byte request layout (TailBlock::wr_t / we_t): two rows of the transposed matrices per request
+                    std::vector<_Float16> wr2((size_t)18 * 384 * 8), we2((size_t)24 * 288 * 8);
+                    for (int p = 0; p < 18; ++p)
+                        for (int t = 0; t < 384; ++t)
+                            for (int e = 0; e < 8; ++e) {
+                                const int cr = t / 12, j4 = t % 12, c = 64 * p + (e < 4 ? 0 : 32) + cr;
+                                wr2[((size_t)p * 384 + t) * 8 + e] = wrt[(size_t)c * csp + 4 * j4 + (e & 3)];
+                            }
+                    for (int p = 0; p < 24; ++p)
+                        for (int t = 0; t < 288; ++t)
+                            for (int e = 0; e < 8; ++e) we2[((size_t)p * 288 + t) * 8 + e] = wet[(size_t)(2 * p + (e < 4 ? 0 : 1)) * B.ce + 4 * t + (e & 3)];
+                    TRY_OR_FREE(dev_upload(bb, &B.t_wr2, wr2));
+                    TRY_OR_FREE(dev_upload(bb, &B.t_we2, we2));
+                }
                 std::vector<float> brp(csp > 32 ? csp : 32, 0.f);
                 for (int j = 0; j < B.cs; ++j) brp[j] = br[j];
                 TRY_OR_FREE(dev_upload(bb, &B.pp_br, brp));
@@ -826,13 +842,13 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         bool ok = NBLK == 16;
         for (int i = 12; i <= 15 && ok; ++i) {
             const BlockW& B = bb->blk[i];
-            ok = ok && B.exp_frag && B.t_wr && B.t_dwp && B.t_wproj && B.H == 7 && B.d.s == 1 && B.d.cin == 192 && B.ce == 1152;
+            ok = ok && B.exp_frag && B.t_wr2 && B.t_we2 && B.t_dwp && B.t_wproj && B.H == 7 && B.d.s == 1 && B.d.cin == 192 && B.ce == 1152;
         }
         if (ok) {
             std::vector<TailBlock> tab(4);
             for (int j = 0; j < 4; ++j) {
                 const BlockW& B = bb->blk[12 + j];
-                tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr, B.se_br, B.t_we, B.se_be, B.t_wproj, B.project.b,
+                tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr2, B.se_br, B.t_we2, B.se_be, B.t_wproj, B.project.b,
                                    B.d.cout, B.d.k};
             }
             TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
