@@ -57,7 +57,8 @@ struct MbArgs {
 struct TailBlock {
     const _Float16* wexp;   // [72][6][64][8] expand weights, MFMA fragment order
     const float* bexp;      // [1152]
-    const uint32_t* dwp;    // [15][1152] depthwise taps as fp16 pairs: slot 3*ky + d; 5x5: (k0,k1),(k2,k3),(k4,0); 3x3: (k0,k1),(k2,0),0
+    const uint32_t* dwp;    // [4][1152][4] dwords: slots 0..14 = depthwise taps as fp16 pairs (slot 3*ky + d; 5x5: (k0,k1),(k2,k3),(k4,0);
+                            // 3x3: (k0,k1),(k2,0),0), slot 15 = the bias (fp32 bits); request j of a channel = slots 4j .. 4j+3
     const float* bdw;       // [1152]
     const _Float16* wr_t;   // [18][384][8] squeeze FC: request p of thread (cr, j4) = Wr^T[64p + cr][4 j4 .. +3], Wr^T[64p + 32 + cr][4 j4 .. +3]
                             // (Wr^T = [1152][48], channel-major; unscaled: 1/(49*log2e) is applied in fp32)

@@ -2148,12 +2148,20 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         const bool ks3 = Wt.ks == 3;
         uint32_t rawA[15], rawB[15];
         float biasA, biasB;
+        // taps + bias of a channel: four 16-byte requests (slots 0..14 = tap pairs, 15 = bias; 1 KB per wave-instruction) instead of 16
+        // dword loads -- a timing-only build without the tap loads ran the depthwise phase in 21.0 k cycles instead of 25.5 k
+        auto load_taps = [&](int ch, uint32_t (&raw)[15], float& bias) {
+            u4v t4[4];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            rawA[i] = 0u;
-            if (i < 9 || !ks3) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + tid) * 4u);
-        }
-        biasA = gload<float>(W.bdw, (unsigned)tid * 4u);
+            for (int j = 0; j < 4; ++j) t4[j] = gload<u4v>(W.dwp, (unsigned)((j * T7_CE + ch) * 16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[4 * j] = t4[j].x; raw[4 * j + 1] = t4[j].y; raw[4 * j + 2] = t4[j].z;
+                if (j < 3) raw[4 * j + 3] = t4[j].w;
+            }
+            bias = __builtin_bit_cast(float, (uint32_t)t4[3].w);
+        };
+        load_taps(tid, rawA, biasA);
         // ---------------- expand: ED = silu(X . Wexp^T + b) ----------------
         {
             h8 xb[4][6];
@@ -2354,14 +2362,10 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             // squeeze FC weights (36 x 8 bytes per thread) and the first half of the excite FC weights (24 x 8 bytes) before
             // the last quarter round (earlier the two tap buffers leave no registers for them: spills); the second half
             // once FC1 has consumed the squeeze weights.
-#pragma unroll
-            for (int i = 0; i < 3 * KS; ++i) rawB[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 512 + tid) * 4u);
-            biasB = gload<float>(W.bdw, (unsigned)(512 + tid) * 4u);
+            load_taps(512 + tid, rawB, biasB);
             dw_round(tid, rawA, biasA);
             const int cl = tid & 127, p4 = tid >> 7, rb = 2 * p4;
-#pragma unroll
-            for (int i = 0; i < 3 * KS; ++i) rawA[i] = gload<uint32_t>(W.dwp, (unsigned)(i * T7_CE + 1024 + cl) * 4u);
-            biasA = gload<float>(W.bdw, (unsigned)(1024 + cl) * 4u);
+            load_taps(1024 + cl, rawA, biasA);
             dw_round(512 + tid, rawB, biasB);
             {
                 const int crl = fc1_thr ? cr : 0;   // idle threads re-read row group 0 (no divergent region around the loads)

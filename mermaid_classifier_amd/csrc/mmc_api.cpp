@@ -163,6 +163,7 @@ struct BlockW {
     // tail7_kernel packing (7x7 blocks 12..14): project weights in plain fragment order, depthwise tap pairs
     _Float16* t_wproj = nullptr;
     uint32_t* t_dwp = nullptr;
+    uint32_t* t_dwp4 = nullptr;  // taps + bias, [4][ce][4] dwords (16-byte requests)
     _Float16* dw_diag = nullptr;  // mid14m_kernel: block-diagonal depthwise fragments [ce/16][NT][64][8] (depthwise on the matrix pipe)
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
     _Float16 *t_wr2 = nullptr, *t_we2 = nullptr; // ... blocks 12-15: paired rows for tail7_kernel's 16-byte requests
@@ -554,6 +555,17 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             dp[(size_t)(ky * 3 + d) * B.ce + c] = u;
                         }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp, dp));
+                // the same 15 dwords + the bias (as the 16th) in 16-byte requests: [4][ce][4] -- request j of channel c holds slots
+                // 4j .. 4j+3; a wave's request is 1 KB contiguous (16 dword loads per thread were 16 wave-instructions of 256 bytes)
+                std::vector<uint32_t> dp4((size_t)16 * B.ce, 0u);
+                for (int c = 0; c < B.ce; ++c)
+                    for (int t = 0; t < 16; ++t) {
+                        uint32_t v = 0u;
+                        if (t < 15) v = dp[(size_t)t * B.ce + c];
+                        else memcpy(&v, &db[c], 4);   // the bias exactly as dw_b holds it
+                        dp4[((size_t)(t / 4) * B.ce + c) * 4 + (t % 4)] = v;
+                    }
+                TRY_OR_FREE(dev_upload(bb, &B.t_dwp4, dp4));
             }
             if (mid14m_enabled && i >= 6 && i <= 10 && H == 14 && B.d.s == 1 && B.ce % 16 == 0) {
                 // Depthwise on the matrix pipe (mid14m_kernel): Y[c][p] = sum_k A[c][k] B[k][p] with k = (tap, channel') and
@@ -848,7 +860,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             std::vector<TailBlock> tab(4);
             for (int j = 0; j < 4; ++j) {
                 const BlockW& B = bb->blk[12 + j];
-                tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp, B.dw_b, B.t_wr2, B.se_br, B.t_we2, B.se_be, B.t_wproj, B.project.b,
+                tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp4, B.dw_b, B.t_wr2, B.se_br, B.t_we2, B.se_be, B.t_wproj, B.project.b,
                                    B.d.cout, B.d.k};
             }
             TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
