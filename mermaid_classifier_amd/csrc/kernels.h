@@ -91,7 +91,7 @@ struct TailArgs {
     const _Float16* pre_X;      // [B][196][112] block 11's input, or null
     const _Float16* pre_wexp;   // [42][4][64][8] expand weights, MFMA fragment order
     const float* pre_bexp;      // [672]
-    const uint32_t* pre_dwp;    // [15][672] depthwise taps as fp16 pairs (layout of TailBlock::dwp)
+    const uint32_t* pre_dwp;    // [4][672][4] depthwise taps as fp16 pairs + bias (layout of TailBlock::dwp)
     const float* pre_bdw;       // [672]
     const _Float16* pre_wproj;  // [12][24][64][8] (k-steps 21..23 zero)
     const float* pre_bproj;     // [192]
@@ -159,7 +159,7 @@ struct Mid14Args {
     const _Float16* X;        // [B][196][Cin]
     const _Float16* wexp;     // [Ce/16][ceil(Cin/32)][64][8] expand weights, MFMA fragment order (K zero padded)
     const float* bexp;        // [Ce]
-    const uint32_t* dwp;      // [15][Ce] depthwise taps as fp16 pairs (layout of TailBlock::dwp)
+    const uint32_t* dwp;      // [4][Ce][4] depthwise taps as fp16 pairs + bias in 16-byte requests (layout of TailBlock::dwp)
     const float* bdw;         // [Ce]
     _Float16* D;              // [B][196][Ce] depthwise output
     float* pool;              // [B][Ce] pool sums

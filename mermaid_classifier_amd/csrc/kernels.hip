@@ -1954,8 +1954,19 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 uint32_t raw[15];
                 const int cg = chunk * CH + cd;   // (waves 6, 7: some channel of the block, unused)
 #pragma unroll
-                for (int i = 0; i < 15; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * 672 + cg) * 4u);
-                const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
+                for (int i = 0; i < 15; ++i) raw[i] = 0u;
+                float dbias;
+                {   // taps + bias in four 16-byte requests (layout [4][672][4]: see the depthwise rounds below)
+                    u4v t4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t4[j] = gload<u4v>(dwp, (unsigned)((j * 672 + cg) * 16));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        raw[4 * j] = t4[j].x; raw[4 * j + 1] = t4[j].y; raw[4 * j + 2] = t4[j].z;
+                        if (j < 3) raw[4 * j + 3] = t4[j].w;
+                    }
+                    dbias = __builtin_bit_cast(float, (uint32_t)t4[3].w);
+                }
                 if (npf == 2) expand_chunk(std::integral_constant<int, 2>{}, chunk);
                 else expand_chunk(std::integral_constant<int, 1>{}, chunk);
                 T7_BAR();
@@ -2702,8 +2713,23 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         uint32_t raw[15];
         const int cg = chunk * CH + cd;
 #pragma unroll
-        for (int i = 0; i < 3 * KSD; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(i * CE + cg) * 4u);
-        const float dbias = gload<float>(bdw, (unsigned)cg * 4u);
+        for (int i = 0; i < 15; ++i) raw[i] = 0u;
+        float dbias;
+        if (KSD == 3) {   // nine dwords + bias: the 3x3 variant sits at exactly 128 registers (two workgroups per CU) and keeps dword loads
+#pragma unroll
+            for (int i = 0; i < 9; ++i) raw[i] = gload<uint32_t>(dwp, (unsigned)(((i >> 2) * CE + cg) * 4 + (i & 3)) * 4u);
+            dbias = gload<float>(bdw, (unsigned)cg * 4u);
+        } else {   // taps + bias in four 16-byte requests (layout [4][CE][4]: slots 0..14 = tap pairs, 15 = bias) instead of 16 dword loads
+            u4v t4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t4[j] = gload<u4v>(dwp, (unsigned)((j * CE + cg) * 16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                raw[4 * j] = t4[j].x; raw[4 * j + 1] = t4[j].y; raw[4 * j + 2] = t4[j].z;
+                if (j < 3) raw[4 * j + 3] = t4[j].w;
+            }
+            dbias = __builtin_bit_cast(float, (uint32_t)t4[3].w);
+        }
         // ---------------- expand: this wave's pixel fragments x the chunk's six 16-channel weight fragments ----------------
         {
             h8 xb[2][CKS];   // (re-read per chunk from L2: holding them across the depthwise phase costs 32 registers)

@@ -1057,7 +1057,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             // the whole of block 11, blocks 12..15 and the head conv in ONE launch: from block 10's output to the feature vector
             TailArgs ta{};
             ta.B = n; ta.blk = bb->tail_tab; ta.nblk = 4;
-            ta.pre_X = x; ta.pre_wexp = B.exp_frag; ta.pre_bexp = B.expand.b; ta.pre_dwp = B.t_dwp; ta.pre_bdw = B.dw_b;
+            ta.pre_X = x; ta.pre_wexp = B.exp_frag; ta.pre_bexp = B.expand.b; ta.pre_dwp = B.t_dwp4; ta.pre_bdw = B.dw_b;
             ta.pre_wr_t = B.t_wr; ta.pre_br = B.pp_br; ta.pre_we_t = B.t_we; ta.pre_be = B.se_be; ta.pre_wproj = bb->pre_wproj;
             ta.pre_bproj = B.project.b; ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
             ta.head_w = bb->head_wfrag; ta.head_b = bb->head.b; ta.feat = out_dev;
@@ -1096,7 +1096,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             }
         } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
             Mid14Args ma{};
-            ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
+            ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp4; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
             ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
             ma.dwdiag = (B.d.s == 1) ? B.dw_diag : nullptr;
             { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (ma.dwdiag ? 2 : (B.d.s == 2 ? 7 : 4)); }
