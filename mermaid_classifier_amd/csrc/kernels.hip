@@ -2094,12 +2094,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         proj_prefetch(wproj, bproj, 24, nf0, nfn, lane, q, pbias, wo, wa);
         T7_BAR();
         if (clk_on) tkk[2] = (long long)__builtin_readcyclecounter();
-        for (int e = tid; e < T7_PIX * 84; e += 512) {
-            const int pix = e / 84, oc = e - pix * 84;
-            uint4* pv = reinterpret_cast<uint4*>(ED + pix * DS + oc * 16);
+        if (tid < 504) {   // 84 groups of 8 channels x 6 pixel residues: the gate values stay in registers (see the blocks' gate pass)
+            const int r6 = tid / 84, oc = tid - 84 * r6;
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
             const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
-            *pv = gate_h8(*pv, g0, g1);
+            unsigned char* pc = ED + oc * 16;
+            for (int k0 = 0; k0 < 9; k0 += 3) {   // three pixels in flight
+                uint4 v[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int pix = r6 + 6 * (k0 + j);
+                    v[j] = *reinterpret_cast<const uint4*>(pc + (pix < T7_PIX ? pix : T7_PIX - 1) * DS);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int pix = r6 + 6 * (k0 + j);
+                    const uint4 o = gate_h8(v[j], g0, g1);
+                    if (pix < T7_PIX) *reinterpret_cast<uint4*>(pc + pix * DS) = o;
+                }
+            }
         }
         T7_BAR();
         if (clk_on) tkk[3] = (long long)__builtin_readcyclecounter();
@@ -2535,12 +2548,28 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             for (int e = tid; e < T7_CE; e += 512) a.dbg_gate[(size_t)b * T7_CE + e] = gate[e];
         }
         // ---------------- gate, in place ----------------
-        for (int e = tid; e < T7_PIX * 144; e += 512) {
-            const int pix = e / 144, oc = e - pix * 144;
-            uint4* pv = reinterpret_cast<uint4*>(ED + pix * T7_ES + oc * 16);
+        // A thread keeps ONE group of 8 channels (its 8 gate values in registers) and walks every third pixel: 144 groups x 3 = 432
+        // threads.  (One (pixel, group) element per thread and step re-read the 32 bytes of gate values for every 16 bytes of
+        // data: the pass is LDS traffic, and two thirds of it was gate.)
+        if (tid < 432) {
+            const int r3 = tid >= 288 ? 2 : (tid >= 144 ? 1 : 0), oc = tid - 144 * r3;
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
             const f4 g1 = *reinterpret_cast<const f4*>(gate + oc * 8 + 4);
-            *pv = gate_h8(*pv, g0, g1);   // fp32 product, one rounding, one VALU op per element
+            unsigned char* pc = ED + oc * 16;
+            for (int k0 = 0; k0 < 17; k0 += 4) {   // four pixels in flight (gate_h8 is asm: the compiler does not unroll around it)
+                uint4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pix = r3 + 3 * (k0 + j);
+                    v[j] = *reinterpret_cast<const uint4*>(pc + (pix < T7_PIX ? pix : T7_PIX - 1) * T7_ES);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pix = r3 + 3 * (k0 + j);
+                    const uint4 o = gate_h8(v[j], g0, g1);   // fp32 product, one rounding, one VALU op per element
+                    if (pix < T7_PIX) *reinterpret_cast<uint4*>(pc + pix * T7_ES) = o;
+                }
+            }
         }
         T7_BAR();
         T7_TICK();
