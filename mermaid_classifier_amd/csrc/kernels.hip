@@ -2736,6 +2736,22 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         unsigned char* zr = smem + (row < ZT * 7 ? row : row + 98) * ES2 + 16 * c16;
         *reinterpret_cast<uint4*>(zr) = uint4{0u, 0u, 0u, 0u};
     }
+    constexpr bool KEEP_XB = KSD == 5 && ST == 1;
+    h8 xb[2][CKS];
+    auto load_xb = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pix = 16 * (pf0 + (i < npf ? i : 0)) + m;
+            const int pixc = pix < HW ? pix : HW - 1;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const int kk = 32 * ks + 8 * q;
+                // zero-padded K columns re-read the last eight channels: finite values against the zero rows the host packs there
+                xb[i][ks] = gload<h8>(xgp, (unsigned)((pixc * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
+            }
+        }
+    };
+    if (KEEP_XB) load_xb();
 #pragma unroll 1
     for (int chunk = blockIdx.y; chunk < NCHK; chunk += gridDim.y) {   // gridDim.y workgroups share a patch's chunks
         // taps and bias of this thread's channel: requested now, used after the expand phase
@@ -2761,21 +2777,10 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
         }
         // ---------------- expand: this wave's pixel fragments x the chunk's six 16-channel weight fragments ----------------
         {
-            h8 xb[2][CKS];   // (re-read per chunk from L2: holding them across the depthwise phase costs 32 registers)
-            {
-                const GLOBAL_AS _Float16* xg = xgp;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pix = 16 * (pf0 + (i < npf ? i : 0)) + m;
-            const int pixc = pix < HW ? pix : HW - 1;
-#pragma unroll
-            for (int ks = 0; ks < CKS; ++ks) {
-                const int kk = 32 * ks + 8 * q;
-                // zero-padded K columns re-read the last eight channels: finite values against the zero rows the host packs there
-                xb[i][ks] = gload<h8>(xg, (unsigned)((pixc * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
-            }
-        }
-    }
+            // 3x3 (128 registers, two workgroups per CU): the pixel fragments are re-read per chunk from L2 -- holding them across the
+            // depthwise phase costs 32 registers.  5x5 (one workgroup per CU, registers to spare): read once, before the chunk loop
+            // (a timing-only build without these loads ran the 5x5 variants 7-10 % faster).
+            if (!KEEP_XB) load_xb();
             // Weight fragments and bias of the next 16-channel fragment are requested one fragment ahead, bias first and pinned
             // (see tail7_kernel's block 11): the wave's role is a template argument and lanes past the last pixel store to a
             // scratch word, so the six fragments of a chunk are one straight-line block.
