@@ -6,8 +6,13 @@
 
 One "step" = one pass of the hot path over one batch of 256 synthetic 224x224 u8 patches per
 GPU (BASELINE.json configs[1]: "EfficientNet-B0 forward, batch=256 random 224x224 patches"),
-resident in HBM before the timed region; for N > 1 ranks hold independent shards (weak scaling)
-and the step ends with the RCCL all-gather of the (N*256, 1280) feature matrix (configs[3]).
+resident in HBM before the timed region; for N > 1 ranks hold independent shards (weak scaling):
+every step's (256, 1280) features land in the rank's block of G*256 rows and the block is
+all-gathered over RCCL ONCE per G steps -- G = K by default, i.e. one gather of the rank's whole
+(K*256, 1280) block at the end, which is what configs[3] describes (one gather of (n/N, 1280)
+blocks); `--gather-every G` with G < K issues the gathers asynchronously behind the next group's
+kernels (double-buffered blocks; MMC_BENCH_OVERLAP=0: synchronous).  Gather buffers are allocated
+once (dist.FeatureGatherer).
 Steps rotate over NBUF distinct input batches (308 MB > the 256 MB Infinity Cache), so the
 compulsory input bytes of a step come from HBM, as they would in a real run.
 Rank 0 prints ONE JSON line.  The oracle is imported only for the cpu_baseline leg.
@@ -110,19 +115,32 @@ def self_launch(n: int) -> int:
                                       stdout=None if r == 0 else sys.stderr))
     status = 0
     try:
-        for r, p in enumerate(procs):
-            rc = p.wait()
-            if rc != 0:
-                print(f"bench.py: rank {r} exited with status {rc}", file=sys.stderr)
-                status = status or (rc if rc > 0 else 1)
-                for q in procs:        # a dead rank leaves the others waiting in a collective
-                    if q.poll() is None:
+        live = dict(enumerate(procs))
+        while live:                    # poll every rank: a dead rank leaves the others waiting in a collective (minutes under RCCL)
+            for r, p in list(live.items()):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                del live[r]
+                if rc != 0:
+                    print(f"bench.py: rank {r} exited with status {rc}", file=sys.stderr)
+                    status = status or (rc if rc > 0 else 1)
+                    for q in live.values():
                         q.terminate()
+            if live:
+                time.sleep(0.05)
     finally:
         for q in procs:
             if q.poll() is None:
                 q.kill()
     return status
+
+
+def gather_desc(world: int, K: int, G: int, overlap: bool, rows: int = BATCH, d: int = 1280) -> str:
+    """Names the gather granularity in config.workload."""
+    n = -(-K // G)
+    return (f"{n} RCCL all-gather{'s' if n > 1 else ''} of ({G * rows}, {d}) fp32 rank blocks (one per {G} steps"
+            + (", issued asynchronously behind the next group's kernels" if overlap else "") + f") x{world} ranks")
 
 
 def dry_run(args, json_out) -> None:
@@ -138,25 +156,54 @@ def dry_run(args, json_out) -> None:
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if os.environ.get("MMC_BENCH_DRY_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole run
         os._exit(3)
-    n_total = world * 5 + (world - 1)            # ragged on purpose
-    lo, hi = shard_range(n_total, rank, world)
-    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1).repeat(1, 8)
+    from mermaid_classifier_amd.dist import FeatureGatherer
+    rows = 5                                     # stand-in for the 256 patches of a step
+    K = max(args.steps, 1)
+    G = K if args.gather_every <= 0 else min(args.gather_every, K)
+    overlap = os.environ.get("MMC_BENCH_OVERLAP", "1") == "1" and G < K
+
+    def run_groups(steps):
+        """The step loop of the real run on rank-tagged rows: step s fills rows of the rank's group block, every G steps (and
+        at the end, ragged) the block is gathered once.  Returns the gathered matrices in order."""
+        outs, pend = [], []
+        s0 = 0
+        while s0 < steps:
+            g = min(G, steps - s0)
+            n_total = world * g * rows + (world - 1)          # ragged on purpose: the first world-1 ranks hold one row more
+            lo, hi = shard_range(n_total, rank, world)
+            block = torch.empty((hi - lo, 8), dtype=torch.float32)
+            for i in range(hi - lo):                          # "extract": row = its global patch index (+ the group's offset)
+                block[i] = float(lo + i + 1000 * (s0 // G))
+            gat = FeatureGatherer(n_total, 8, block)
+            if overlap:
+                work, fin = gat.gather(block, async_op=True)
+                pend.append((work, fin, n_total, s0 // G))
+            else:
+                outs.append((gat.gather(block), n_total, s0 // G))
+            s0 += g
+        for work, fin, n_total, gi in pend:
+            work.wait()
+            outs.append((fin(), n_total, gi))
+        return outs
+
     for _ in range(args.warmup):
-        gather_features(local, n_total)
+        gather_features(torch.zeros((shard_range(world + 1, rank, world)[1] - shard_range(world + 1, rank, world)[0], 8)), world + 1)
     dist.barrier()
     t0 = time.perf_counter()
-    full = gather_features(local, n_total)
-    for _ in range(args.steps - 1):
-        full = gather_features(local, n_total)
+    outs = run_groups(K)
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ok = full.shape == (n_total, 8) and bool(torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32)))
+    ok = len(outs) == -(-K // G)
+    for full, n_total, gi in outs:
+        ok = ok and full.shape == (n_total, 8) and bool(torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32) + 1000 * gi))
     if rank == 0:
         print(json.dumps({"metric": "patches/sec (224x224 EfficientNet-B0)", "value": None, "unit": "patches/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "none (dry run)",
-                          "config": {"workload": "dry run: launcher + gloo rendezvous + ragged all-gather of rank-tagged blocks, no GPU work",
+                          "config": {"workload": "dry run: launcher + gloo rendezvous + ragged all-gather of rank-tagged blocks, no GPU work; "
+                                                 + gather_desc(world, K, G, overlap, rows, 8),
+                                     "gather_every_steps": G, "gathers_per_run": -(-K // G), "gather_overlap": overlap,
                                      "parallelism": f"patch-sharded x{world}"}, "dry_run": True, "gather_ok": ok}),
               file=json_out, flush=True)
     dist.barrier()
@@ -172,6 +219,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-passes", type=int, default=5)
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="N > 1: all-gather the rank block once per this many steps (0 = once, at the end, over all K steps' rows)")
+    ap.add_argument("--spread-blocks", type=int, default=3, help="timed blocks of --steps for the spread (the first one is `value`)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / gather plumbing on gloo, no GPU work")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -214,76 +264,112 @@ def main():
     patches = pbufs[0]
     feats = torch.empty((BATCH, 1280), dtype=torch.float32, device=dev)
 
-    from mermaid_classifier_amd.dist import gather_features
+    from mermaid_classifier_amd.dist import FeatureGatherer
 
-    # N > 1: one RCCL all-gather per step, by default on the same stream right after the extract.  MMC_BENCH_OVERLAP=1 (opt-in,
-    # unmeasured on > 1 GPU: at world size 1 it costs 2 %) issues it asynchronously on RCCL's own stream while the next step's
-    # kernels run: feature / gathered buffers are double-buffered, a buffer is reused only after the all-gather that read it
-    # has been waited for, and every outstanding collective is waited for before the clock stops.
+    # N > 1 (configs[3]): a step's features go into the rank's block of G * 256 rows; the block is all-gathered ONCE per G steps,
+    # G = K by default (one gather of the rank's whole block at the end).  With G < K the gather of group g is issued
+    # asynchronously on RCCL's stream while group g + 1 computes (two blocks / two receive matrices, a block is refilled only after
+    # the gather that read it has been waited for); MMC_BENCH_OVERLAP=0 makes it synchronous.  Every buffer is allocated here, once.
     use_dist = world > 1 or os.environ.get("MMC_BENCH_FORCE_DIST") == "1"
     if use_dist and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    overlap = use_dist and os.environ.get("MMC_BENCH_OVERLAP", "0") == "1"
-    fbuf = [feats, torch.empty_like(feats)] if overlap else [feats]
-    gbuf = [torch.empty((world * BATCH, 1280), dtype=torch.float32, device=dev) for _ in fbuf] if overlap else []
-    pending = [None, None]
-    counter = [0]
+    K = args.steps
+    G = K if args.gather_every <= 0 else min(args.gather_every, K)
+    overlap = use_dist and G < K and os.environ.get("MMC_BENCH_OVERLAP", "1") == "1"
+    nblk = 2 if overlap else 1
+    blocks = [torch.empty((G * BATCH, 1280), dtype=torch.float32, device=dev) for _ in range(nblk)] if use_dist else []
+    gats = [FeatureGatherer(world * G * BATCH, 1280, blocks[0]) for _ in range(nblk)] if use_dist else []
+    tailg = None                                   # the last, shorter group when G does not divide K
+    if use_dist and K % G:
+        tailg = FeatureGatherer(world * (K % G) * BATCH, 1280, blocks[0])
+    pending = [None] * nblk
+    state = {"in": 0, "s": 0}
+
+    def wait_block(i):
+        if pending[i] is not None:
+            pending[i].wait()          # stream-level wait for the collective that read blocks[i]
+            pending[i] = None
 
     def step():
-        src = pbufs[counter[0] % NBUF]     # a fresh batch every step: input bytes come from HBM, not from the Infinity Cache
-        if not overlap:
-            counter[0] += 1
-            bb.extract(src, out=feats)
-            if use_dist:
-                gather_features(feats, world * BATCH)   # one RCCL all-gather of the (BATCH,1280) blocks
+        src = pbufs[state["in"] % NBUF]    # a fresh batch every step: input bytes come from HBM, not from the Infinity Cache
+        state["in"] += 1
+        bb.extract(src, out=feats)
+        if not use_dist:
             return
-        i = counter[0] & 1
-        counter[0] += 1
-        if pending[i] is not None:
-            pending[i].wait()          # the collective that read fbuf[i] / wrote gbuf[i] two steps ago (stream-level wait)
-        bb.extract(src, out=fbuf[i])
-        pending[i] = dist.all_gather_into_tensor(gbuf[i], fbuf[i], async_op=True)
+        s = state["s"]
+        gi, k = divmod(s, G)
+        i = gi % nblk
+        if k == 0:
+            wait_block(i)
+        blocks[i][k * BATCH:(k + 1) * BATCH].copy_(feats, non_blocking=True)     # same stream, right behind the pass
+        state["s"] = s + 1
+        last = s + 1 == K
+        if k + 1 == G or last:
+            g = gats[i] if k + 1 == G else tailg
+            send = blocks[i] if k + 1 == G else blocks[i][: (k + 1) * BATCH]
+            if overlap and not last:
+                pending[i], _ = g.gather(send, async_op=True)
+            else:
+                g.gather(send)
+        if last:
+            state["s"] = 0
 
     def drain():
-        for i in (0, 1):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+        for i in range(nblk):
+            wait_block(i)
 
     # Engine initialisation, before the W warm-up steps: the library captures a pass into a HIP graph the third time the same
     # buffers come in (mmc_api.cpp run_pass) -- a one-off cost of a few ms that belongs to set-up like the weights upload, so
-    # that a small W cannot push it into the timed region.
-    for _ in range(3 * NBUF * (2 if overlap else 1)):   # every (input, output) combination seen three times: its graph exists
-        step()
+    # that a small W cannot push it into the timed region.  The RCCL communicator and every gather buffer are warmed the same
+    # way (the first collective creates the communicator: hundreds of ms).
+    for _ in range(3 * NBUF):          # every (input, output) combination seen three times: its graph exists
+        bb.extract(pbufs[state["in"] % NBUF], out=feats)
+        state["in"] += 1
+    if use_dist:
+        for g, blk in zip(gats, blocks):
+            g.gather(blk)
+        if tailg is not None:
+            tailg.gather(blocks[0][: (K % G) * BATCH])
     for _ in range(args.warmup):
-        step()
-    drain()
+        bb.extract(pbufs[state["in"] % NBUF], out=feats)
+        state["in"] += 1
+
+    def timed_block():
+        drain()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        drain()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # `value` comes from the FIRST block of exactly K steps (the contract); the further blocks only feed `spread`.
+    times = [timed_block() for _ in range(max(1, args.spread_blocks))]
+    elapsed = times[0]
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if overlap:
-        feats = fbuf[(counter[0] - 1) & 1]
-        if not torch.equal(gbuf[(counter[0] - 1) & 1][rank * BATCH:(rank + 1) * BATCH], feats):
+        lastg = tailg if tailg is not None else gats[((K - 1) // G) % nblk]
+        nrows = ((K % G) or G) * BATCH
+        mine = lastg.out[rank * nrows:(rank + 1) * nrows]
+        if not torch.equal(mine[-BATCH:], feats):
             raise SystemExit("gathered feature block differs from the local features")
     if not np.isfinite(feats.float().sum().item()):
         raise SystemExit("non-finite features")
 
     if rank == 0:
         value = world * BATCH * args.steps / elapsed
+        vals = [world * BATCH * args.steps / t for t in times]
         # per-kernel durations, HIP events on the launch stream, same resident workload
         per_kernel = defaultdict(lambda: [0.0, 0, 0, 0])  # ms, launches, algorithmic bytes, algorithmic flops
         sub = -(-BATCH // bb.lanes)   # each launch of the schedule covers one lane's sub-batch
@@ -308,7 +394,7 @@ def main():
         tot = schedule.totals(BATCH, launched)
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/summarize_profiles.py), if present
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             pmc = sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"))[-1]
             table = json.loads(pmc.read_text())
@@ -318,10 +404,11 @@ def main():
                     and (("<" not in dom) or ("<" in k and targs(k) == targs(dom)))]
             if hits:
                 traffic = sum(h["read_bytes_per_launch"] + h["write_bytes_per_launch"] for h in hits) / len(hits)
+                traffic_source = f"profiles/{pmc.name} (committed rocprofv3 --pmc passes of this command, not measured in this run)"
         except Exception:
-            traffic = None
+            traffic, traffic_source = None, None
         roofline = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": unit,
-                    "frac": achieved / peak, "traffic": traffic,
+                    "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
                     "patches_per_launch": sub,
                     "alg_bytes_per_launch": nbytes / launches, "alg_flops_per_launch": nflops / launches,
@@ -333,11 +420,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "spread": {"unit": "patches/s", "blocks": len(times), "steps_per_block": K,
+                       "min": min(vals), "median": float(np.median(vals)), "max": max(vals)},
             "config": {"workload": "EfficientNet-B0 forward, batch=256 random 224x224 u8 patches per GPU -> (256,1280) fp32"
-                                   + ("; RCCL all-gather of features" + (" overlapped with the next step" if overlap else "") if world > 1 else ""),
+                                   + ("; " + gather_desc(world, K, G, overlap) if use_dist else ""),
                        "per_gpu_batch": BATCH, "global_batch": world * BATCH, "weights": "synthetic seed 0",
                        "input_batches_rotated": NBUF,
                        "lanes_per_gpu": bb.lanes,
+                       **({"gather_every_steps": G, "gathers_per_run": -(-K // G), "gather_overlap": overlap} if use_dist else {}),
                        "parallelism": f"patch-sharded x{world}"},
             "roofline": roofline,
         }

@@ -82,10 +82,16 @@ size_t mmc_backbone_workspace_bytes(const mmc_backbone* bb);
  * stream.
  * When the same (patches, out_features, n) combination comes in repeatedly the pass is captured into a HIP graph
  * once and replayed on `hip_stream` afterwards (env MMC_GRAPH=0 disables); results are identical either way.  The 32
- * most recently used combinations keep their graph; callers that cycle through more buffers than that fall back to plain
- * launches for the evicted ones until they repeat. */
+ * most recently used combinations keep their graph.  A combination whose graph was evicted runs as plain launches from
+ * then on (it is not captured a second time), and after 32 evictions -- one full turnover of the cache -- no further
+ * combination is captured: a caller that cycles through more buffers than the cache holds pays plain launches, never a
+ * capture per call. */
 int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,
                          unsigned flags, void* hip_stream);
+
+/* Debug hook for the graph cache above: stats[0] = graphs captured so far, stats[1] = graphs evicted so far,
+ * stats[2] = graphs cached now.  (No reference counterpart: the reference has no launch graphs.) */
+int mmc_backbone_graph_stats(mmc_backbone* bb, int64_t stats[3]);
 
 /* Debug/parity hook: copy one intermediate activation of the LAST internal pass to host.
  * name: "stem", "b<i>.expand", "b<i>.dw", "b<i>.gate", "b<i>.out".  fp16 NHWC tensors are returned

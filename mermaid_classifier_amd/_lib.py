@@ -20,7 +20,7 @@ SYMBOLS = [
     "mmc_last_error", "mmc_version", "mmc_device_count",
     "mmc_backbone_create", "mmc_backbone_destroy", "mmc_feature_dim", "mmc_backbone_max_batch", "mmc_backbone_lanes",
     "mmc_backbone_workspace_bytes", "mmc_backbone_extract", "mmc_backbone_read_activation",
-    "mmc_backbone_profile", "mmc_crop_patches",
+    "mmc_backbone_profile", "mmc_backbone_graph_stats", "mmc_crop_patches",
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
     "mmc_trainer_create", "mmc_trainer_destroy", "mmc_trainer_partial_fit", "mmc_trainer_partial_fit_ordered", "mmc_trainer_get_params", "mmc_trainer_adam_state",
     "mmc_trainer_logits",
@@ -70,6 +70,8 @@ def _load() -> C.CDLL:
     lib.mmc_backbone_read_activation.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
     lib.mmc_backbone_profile.restype = i32
     lib.mmc_backbone_profile.argtypes = [vp, vp, i64, vp, vp, vp, fp, C.POINTER(i32), i32, C.POINTER(i32)]
+    lib.mmc_backbone_graph_stats.restype = i32
+    lib.mmc_backbone_graph_stats.argtypes = [vp, C.POINTER(i64)]
     lib.mmc_crop_patches.restype = i32
     lib.mmc_crop_patches.argtypes = [vp, i32, i32, vp, i64, vp, u32, i32, vp]
     lib.mmc_head_create.restype = i32

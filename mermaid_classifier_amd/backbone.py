@@ -132,6 +132,12 @@ class Backbone:
         _lib.check(_lib.lib().mmc_backbone_read_activation(self._h, name.encode(), out.ctypes.data, capacity, C.byref(nw)))
         return out[:nw.value]
 
+    def graph_stats(self) -> dict:
+        """HIP-graph cache counters of this handle (include/mmc.h mmc_backbone_graph_stats)."""
+        st = (C.c_int64 * 3)()
+        _lib.check(_lib.lib().mmc_backbone_graph_stats(self._h, st))
+        return {"captures": int(st[0]), "evictions": int(st[1]), "cached": int(st[2])}
+
     def profile(self, patches_dev, out_dev) -> List[Tuple[str, float]]:
         """One pass with HIP events around every launch -> [(launch name, ms)]."""
         cap = 128

@@ -122,23 +122,6 @@ struct Mb1Args {
 };
 int launch_mb1(const Mb1Args& a, hipStream_t st);
 
-// Block 2's gate + project + skip inside block 3's front half (mb3_kernel)
-struct Mb3Args {
-    const _Float16* D2;       // [B][56][56][144] block 2's depthwise output
-    const _Float16* pre_w;    // [2][5][64][8] block 2's project conv as MFMA A fragments (n tile, k-step; rows >= 24 and k >= 144 zero)
-    const float* pre_b;       // [32] (24 used, rest zero)
-    const float* pre_gate;    // [B][144] block 2's squeeze-excite gate
-    const _Float16* pre_res;  // [B][56][56][24] block 2's skip input (block 1's output)
-    const _Float16* wexp;     // [9][64][8] block 3's expand weights as MFMA B fragments, K slots permuted (see mb3_kernel)
-    const float* bexp;        // [144]
-    const uint32_t* dwp;      // [15][144] depthwise taps as fp16 pairs
-    const float* bdw;         // [144]
-    _Float16* D;              // [B][28][28][144]
-    float* pool;              // [B][8][144]
-    int B;
-};
-int launch_mb3(const Mb3Args& a, hipStream_t st);
-
 // Front half of a stride-1 MBConv block on 14x28 output tiles (mbt_kernel: b2, b4)
 struct MbtArgs {
     const _Float16* X;        // [B][H][H][Cin]
@@ -152,6 +135,7 @@ struct MbtArgs {
     int stride;               // 1 (b2, b4: D is [B][H][H][Ce]) or 2 (b3, b5: D is [B][H/2][H/2][Ce], mbt2_kernel)
 };
 int launch_mbt(const MbtArgs& a, hipStream_t st);
+int thin_proj_has(int ksteps);                          // 1 when launch_thin_proj has an instantiation for this many k-steps
 int mbt_has(int H, int ks, int stride, int Cin, int Ce);   // 1 when launch_mbt has an instantiation for this layer
 
 // Front half of a 14x14 MBConv block for one patch per workgroup (mid14_kernel)
@@ -166,7 +150,7 @@ struct Mid14Args {
     int B, Cin, Ce, ks;
     int nsplit;               // workgroups per patch (each takes every nsplit-th chunk of 96 channels)
     int stride;               // 1, or 2 (block 11: D is [B][49][Ce])
-    float* dbg_clk;           // optional [B][8 workgroups][8]: shader cycles of the first chunk's phases (MMC_TAIL_CLK=1)
+    float* dbg_clk;           // optional [B][8 workgroups][16]: shader cycles of the first chunk's phases (MMC_TAIL_CLK=1)
     const _Float16* dwdiag;   // optional [Ce/16][NT][64][8]: block-diagonal depthwise fragments (NT = 13 for 5x5, 5 for 3x3) -> mid14m_kernel
 };
 int launch_mid14(const Mid14Args& a, hipStream_t st);

@@ -3730,224 +3730,6 @@ __global__ __launch_bounds__(512) void mbt2_kernel(MbtArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// mb3_kernel: block 2's SE-scale + project conv (+ skip) INSIDE block 3's front half (mbt2_kernel<5, 1, 144, 56>'s recipe), as
-// mb1_kernel does for blocks 0 / 1.  Block 2's output (56x56x24) is only read by block 3 (stride 2: no skip of its own), so it
-// never goes to HBM and the pw_gemm launch that produced it (43 us per 128 patches: 115 MB read, 19 MB written, 19 MB re-read by
-// the next kernel) is gone.  One workgroup (512 threads) = (patch, output tile of 7 x 14), walking the three 48-channel chunks:
-//   project  wave w owns the 16-position window fragments w, w+8, ...: block 2's depthwise output D2[pos][144] is read straight
-//            into registers as the B operand of a swapped MFMA (five k-steps, the next fragment's loads in flight) against the
-//            project weights, which carry the squeeze-excite gate (scaled once per workgroup: 80 v_fma_mix instead of 40 per
-//            fragment); a lane ends up with channels 4q .. 4q+3 and 16+4q .. 16+4q+3 of pixel m, adds the skip input, rounds to
-//            fp16 as the separate path stores block 2's output, and that h8 IS the A operand of the expand MFMA (the expand
-//            weights are packed on the host with their K slots permuted to match: slot 8q+j <- channel 4q+j, 16+4q+j-4).
-//   expand / depthwise 5x5 stride 2 / pool sums: as mbt2_kernel.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void mb3_kernel(Mb3Args a)
-{
-    constexpr int KSD = 5, HIMG = 56, CE = 144, NIP = 3, NROWS = 17, CH = 48, ES2 = 224;
-    constexpr int WW = 32, NPOS = NROWS * WW, NPF = (NPOS + 15) / 16, NS = (NPF + 7) / 8;   // 544 positions, 34 fragments, 5 per wave
-    constexpr int HOUT = 28, TX = 2, NPR = 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* E = smem;                                            // [NS*8*8][ES2]
-    float* pred = reinterpret_cast<float*>(smem + NS * 64 * ES2);       // [7][48]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, q = lane >> 4;
-    const int tile = blockIdx.x, b = blockIdx.z;
-    const int ty = tile / TX, tx = tile - ty * TX;
-    const int oy0 = 7 * ty, ox0 = 14 * tx;
-    const int wy0 = 2 * oy0 - 1;                                        // may be -1: that row is padding
-    int wx0 = (2 * ox0 - 1) & ~1;
-    wx0 = wx0 < 0 ? 0 : wx0;
-    const int pbase = (2 * ox0 - 1 - wx0 - 1) >> 1;   // window pair of output column 0's first tap pair (-1: left padding)
-    const GLOBAL_AS _Float16* d2g = sgpr_ptr<_Float16>(a.D2) + (size_t)b * HIMG * HIMG * CE;
-    const GLOBAL_AS _Float16* resg = sgpr_ptr<_Float16>(a.pre_res) + (size_t)b * HIMG * HIMG * 24;
-    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
-    // ---------------- block 2's gate + project + skip, ONCE per tile ----------------
-    bool okp[NS][2];
-    h8 xbp[NS];       // block 2's output fragment as the expand's A operand (slot 8q+j: channel 4q+j, j < 4; 16+4q+j-4, j >= 4, q < 2)
-    {
-        h8 wg[2][5];
-        {
-            const GLOBAL_AS _Float16* pw = sgpr_ptr<_Float16>(a.pre_w);
-            const GLOBAL_AS float* gg = sgpr_ptr<float>(a.pre_gate) + (size_t)b * CE;
-#pragma unroll
-            for (int ks = 0; ks < 5; ++ks) {
-                const int kk = 32 * ks + 8 * q < CE ? 32 * ks + 8 * q : CE - 8;   // (k >= 144: zero weight columns, any gate)
-                const f4 g0 = gload<f4>(gg, (unsigned)kk * 4u), g1 = gload<f4>(gg, (unsigned)(kk + 4) * 4u);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const u4v w4 = gload<u4v>(pw, (unsigned)(((t * 5 + ks) * 64 + lane) * 16));
-                    const uint4 w = {w4.x, w4.y, w4.z, w4.w};
-                    const uint4 gw = gate_h8(w, g0, g1);
-                    wg[t][ks] = *reinterpret_cast<const h8*>(&gw);
-                }
-            }
-        }
-        const f4 bp0 = *reinterpret_cast<const f4*>(a.pre_b + 4 * q), bp1 = *reinterpret_cast<const f4*>(a.pre_b + 16 + 4 * q);
-        h8 dA[5], dB[5];
-        h4 rA[2], rB[2];
-        auto request = [&](int i, h8 (&d)[5], h4 (&r)[2]) {
-            const int p = 16 * (wave + 8 * i) + m;
-            const int pr = p >> 5, pc = p & 31;
-            const int iy = wy0 + pr, ix = wx0 + pc;
-            const bool ok = p < NPOS && iy >= 0 && iy < HIMG && ix < HIMG;
-            const int row = ok ? iy * HIMG + ix : 0;
-#pragma unroll
-            for (int ks = 0; ks < 5; ++ks) {
-                const int kk = 32 * ks + 8 * q < CE ? 32 * ks + 8 * q : CE - 8;
-                d[ks] = gload<h8>(d2g, (unsigned)((row * CE + kk) * 2));
-            }
-            r[0] = gload<h4>(resg, (unsigned)((row * 24 + 4 * q) * 2));
-            r[1] = gload<h4>(resg, (unsigned)((row * 24 + (q < 2 ? 16 + 4 * q : 20)) * 2));   // (q >= 2: unused slots, zero expand weights)
-        };
-        auto project = [&](int i, const h8 (&d)[5], const h4 (&r)[2]) {
-            f4 c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[0][0], d[0], bp0, 0, 0, 0);
-            f4 c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[1][0], d[0], bp1, 0, 0, 0);
-#pragma unroll
-            for (int ks = 1; ks < 5; ++ks) {
-                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[0][ks], d[ks], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[1][ks], d[ks], c1, 0, 0, 0);
-            }
-            h8 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = (_Float16)(c0[j] + (float)r[0][j]);
-                v[4 + j] = (_Float16)(c1[j] + (float)r[1][j]);
-            }
-            xbp[i] = v;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pp = 16 * (wave + 8 * i) + 4 * q + 2 * h;
-                const int pr = pp >> 5, pc = pp & 31;
-                const int py = wy0 + pr;
-                okp[i][h] = pp < NPOS && py >= 0 && py < HIMG && wx0 + pc < HIMG;
-            }
-        };
-        request(0, dA, rA);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            if (wave + 8 * i >= NPF) continue;   // wave-uniform (only the last slot)
-            if (i & 1) {
-                if (i + 1 < NS && wave + 8 * (i + 1) < NPF) request(i + 1, dA, rA);
-                PIN_VMEM();
-                project(i, dB, rB);
-            } else {
-                if (i + 1 < NS && wave + 8 * (i + 1) < NPF) request(i + 1, dB, rB);
-                PIN_VMEM();
-                project(i, dA, rA);
-            }
-        }
-    }
-    // operands of a chunk: three expand weight fragments + biases, this thread's depthwise taps + bias; the next chunk's are requested
-    // in front of the current chunk's depthwise phase (fragments) and behind its window loads (taps)
-    h8 wa[3];
-    float ba[3];
-    uint32_t raw[15];
-    float dbias;
-    auto request_chunk = [&](int chunk) {
-#pragma unroll
-        for (int nf = 0; nf < 3; ++nf) {
-            const int nfg = 3 * chunk + nf;
-            wa[nf] = gload<h8>(wexp, (unsigned)((nfg * 64 + lane) * 16));
-            ba[nf] = a.bexp[16 * nfg + m];
-        }
-    };
-    auto request_taps = [&](int chunk) {
-        const int cg_dw = chunk * CH + tid % CH;
-#pragma unroll
-        for (int i = 0; i < 15; ++i) raw[i] = a.dwp[(size_t)i * CE + cg_dw];
-        dbias = a.bdw[cg_dw];
-    };
-    request_chunk(0);
-    request_taps(0);
-#pragma unroll 1
-    for (int chunk = 0; chunk < 3; ++chunk) {
-        // ---------------- expand ----------------
-        f4 ba4[3];
-#pragma unroll
-        for (int nf = 0; nf < 3; ++nf) ba4[nf] = f4{ba[nf], ba[nf], ba[nf], ba[nf]};
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            if (wave + 8 * i >= NPF) continue;   // wave-uniform
-            const int pair0 = 8 * (wave + 8 * i) + 2 * q;
-            float t[12];
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf) {
-                const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xbp[i], wa[nf], ba4[nf], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
-            }
-            silu_scaled_staged(t);
-#pragma unroll
-            for (int nf = 0; nf < 3; ++nf) {
-                const h2 p0 = {(_Float16)t[4 * nf], (_Float16)t[4 * nf + 1]};
-                const h2 p1 = {(_Float16)t[4 * nf + 2], (_Float16)t[4 * nf + 3]};
-                const h2 z = {(_Float16)0.0f, (_Float16)0.0f};
-                unsigned char* dst = E + pair0 * ES2 + (16 * nf + m) * 4;
-                *reinterpret_cast<h2*>(dst) = okp[i][0] ? p0 : z;
-                *reinterpret_cast<h2*>(dst + ES2) = okp[i][1] ? p1 : z;
-            }
-        }
-        if (chunk + 1 < 3) request_chunk(chunk + 1);   // lands during the depthwise phase
-        T7_BAR();
-        // ---------------- depthwise 5x5 stride 2 (waves 0..5: 7 output rows x 48 channels) ----------------
-        if (wave < 6) {
-            const int c = tid % CH, orow = tid < 7 * CH ? tid / CH : 6;
-            const int cg = chunk * CH + c;
-            uint32_t wq[KSD][3];
-#pragma unroll
-            for (int ky = 0; ky < KSD; ++ky) {
-                const uint32_t r0 = raw[3 * ky], r1 = raw[3 * ky + 1], r2 = raw[3 * ky + 2];
-                wq[ky][0] = r0 << 16; wq[ky][1] = __builtin_amdgcn_alignbit(r1, r0, 16); wq[ky][2] = __builtin_amdgcn_alignbit(r2, r1, 16);
-            }
-            const float dbias_c = dbias;
-            const bool lok = pbase >= 0;    // (pbase + 15 < 16 always: only the left border pair can fall outside the window)
-            const unsigned char* col = E + 4 * c + (lok ? pbase : 0) * ES2;
-            const int o0 = lok ? 0 : -ES2;
-            uint32_t P[KSD][NPR];
-#pragma unroll
-            for (int ky = 0; ky < KSD; ++ky) {
-                const unsigned char* rowp = col + ((2 * orow + ky) * (WW / 2)) * ES2;
-                const uint32_t v0 = *reinterpret_cast<const uint32_t*>(rowp);
-                P[ky][0] = lok ? v0 : 0u;
-#pragma unroll
-                for (int l = 1; l < NPR; ++l) P[ky][l] = *reinterpret_cast<const uint32_t*>(rowp + o0 + l * ES2);
-            }
-            if (chunk + 1 < 3) request_taps(chunk + 1);
-            float acc[14];
-#pragma unroll
-            for (int ky = 0; ky < KSD; ++ky)
-#pragma unroll
-                for (int ip = 0; ip < NIP; ++ip)
-#pragma unroll
-                    for (int j = 0; j < 14; ++j) {
-                        if (ky == 0 && ip == 0) acc[j] = dot2_from(P[ky][j + ip], wq[ky][ip], dbias_c);
-                        else acc[j] = __builtin_amdgcn_fdot2(*reinterpret_cast<const h2*>(&P[ky][j + ip]), *reinterpret_cast<const h2*>(&wq[ky][ip]), acc[j], false);
-                    }
-            f2 psum2 = {0.f, 0.f};
-            uint16_t* dg = reinterpret_cast<uint16_t*>(a.D + (((size_t)b * HOUT + oy0 + orow) * HOUT + ox0) * CE + cg);
-            silu_scaled_staged(acc);
-#pragma unroll
-            for (int j = 0; j < 14; j += 2) {
-                const f2 v = {acc[j], acc[j + 1]};
-                psum2 = psum2 + v;
-                const uint32_t hv = cvt_pk_f16(acc[j], acc[j + 1]);
-                dg[(size_t)j * CE] = (uint16_t)hv;
-                dg[(size_t)(j + 1) * CE] = (uint16_t)(hv >> 16);
-            }
-            pred[orow * CH + c] = psum2.x + psum2.y;
-        } else if (chunk + 1 < 3) request_taps(chunk + 1);   // (waves 6, 7 keep their registers in step; the values are unused)
-        T7_BAR();   // E and pred are free again behind this barrier
-        if (tid < CH) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 7; ++w) s += pred[w * CH + tid];
-            a.pool[((size_t)b * 8 + tile) * CE + chunk * CH + tid] = s;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // proj_patch_kernel: squeeze-excite + project conv (+ residual) of ONE patch per workgroup, for the 28x28 and
 // 14x14 blocks (b3..b10).  There the separate path is launch- and latency-bound (an SE launch of ~10 us plus a
 // project GEMM whose workgroups each do a few dozen MFMAs); with the whole patch in one workgroup
@@ -4564,6 +4346,8 @@ int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
 #undef CASE_NT
 }
 
+int thin_proj_has(int ksteps) { return ksteps >= 1 && ksteps <= 6; }   // the k-step counts launch_thin_proj instantiates
+
 int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
 {
     // pack_pw layout with nt = 2, one chunk; whole 16-pixel fragments; 8-channel lanes
@@ -4584,6 +4368,8 @@ int launch_thin_proj(const GemmArgs& a, int patches, hipStream_t st)
     else if (ks == 2) TP_GO(2, false);
     else if (ks == 3 && a.res) TP_GO(3, true);
     else if (ks == 3) TP_GO(3, false);
+    else if (ks == 4 && a.res) TP_GO(4, true);
+    else if (ks == 4) TP_GO(4, false);
     else if (ks == 5 && a.res) TP_GO(5, true);
     else if (ks == 5) TP_GO(5, false);
     else if (ks == 6 && a.res) TP_GO(6, true);
@@ -4859,7 +4645,6 @@ template <int KS, int NF, int HW, bool RES>
 static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 {
     const int lds = NF * KS * 1024 + 2 * 32 * KS * 4 + 128 + 64 * 28 * 4;   // project weights, pooled + gate vectors, squeeze activations, FC1 partials
-    if (NF * KS * 1024 < (64 * 32 + 32) * 4) return -10;   // FC1 scratch aliases the weight image
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_patch_kernel<KS, NF, HW, RES>),
@@ -4874,7 +4659,8 @@ static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
 {
-    if (a.B < 1 || a.CSP < 4 || a.CSP > 32 || (a.CSP & 3) || a.nparts < 1) return -11;
+    // CSP <= 28: FC1's partial rows have stride PST = 28 and wave 7 (threads 448..) must have no part in FC1 (G = CSP / 4 <= 7)
+    if (a.B < 1 || a.CSP < 4 || a.CSP > 28 || (a.CSP & 3) || a.nparts < 1) return -11;
     const int ks = proj_patch_ksteps(a.K), nf = (a.N + 15) / 16;
 #define PP_CASE(KS_, NF_, HW_, RES_) \
     if (ks == KS_ && nf == NF_ && a.HW == HW_ && (a.res != nullptr) == RES_) return launch_proj_patch_t<KS_, NF_, HW_, RES_>(a, st);
@@ -5026,21 +4812,6 @@ int launch_mbt(const MbtArgs& a, hipStream_t st)
     if (a.H == 56 && a.ks == 3 && a.Cin == 32 && a.Ce == 192) return launch_mbt_t<3, 1, 192, 56>(a, st);   // B4 b3-b5
     if (a.H == 28 && a.ks == 5 && a.Cin == 56 && a.Ce == 336) return launch_mbt_t<5, 2, 336, 28>(a, st);   // B4 b7-b9
     return -5;
-}
-
-int launch_mb3(const Mb3Args& a, hipStream_t st)
-{
-    if (a.B < 1) return -16;
-    const int lds = 5 * 64 * 224 + 7 * 48 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mb3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(mb3_kernel, dim3(8, 1, a.B), dim3(512), lds, st, a);   // one workgroup per (tile, patch): walks the three channel chunks
-    LAUNCH_CHECK();
-    return 0;
 }
 
 // the layer shapes launch_mbt has an instantiation for

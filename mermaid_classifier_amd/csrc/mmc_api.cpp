@@ -239,6 +239,12 @@ struct mmc_backbone {
     // reuse their buffers (bench, BatchedExtractor's chunks, torch's caching allocator) get graphs, others plain launches
     struct SeenKey { const void* in; float* out; int n; };
     std::vector<SeenKey> seen;
+    // combinations whose graph was evicted are NOT captured again (they run as plain launches from then on): a caller that
+    // cycles through more combinations than the cache holds would otherwise pay capture + instantiate + destroy on every call.
+    // After one full turnover of the cache (MMC_GRAPH_CACHE evictions) no new combination is captured at all.
+    std::vector<SeenKey> evicted;
+    int evictions = 0;
+    long long captures = 0;
     hipStream_t gstream = nullptr;
     int nlanes = 1, lane_cap = 0;
     hipEvent_t fork = nullptr;
@@ -263,8 +269,6 @@ struct mmc_backbone {
     bool thin_proj = true;           // B4 blocks 0/1: thin_proj_kernel instead of pw_gemm for the tiny-K project convs (MMC_THIN_PROJ=0)
     bool se_small = true;            // light per-patch squeeze-excite kernel for the early blocks (MMC_SE_SMALL=0: se_fused)
     _Float16 *b0_pre_w = nullptr, *b1_exp_pre = nullptr;
-    _Float16 *b2_pre_w = nullptr, *b3_exp_pre = nullptr;   // block 2's project / block 3's expand for mb3_kernel
-    bool fuse_b2b3 = false;          // block 2's project inside block 3's front half (MMC_FUSE_B2=1; off by default: slower)
     bool tail_full = false;
     bool tail_b11 = false;           // block 11's front half (expand + depthwise stride 2) inside tail7_kernel too: no b11 launch at all
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
@@ -434,10 +438,12 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     if (bb->keep) { int r__ = dev_alloc(bb, &bb->dbg_clk, (size_t)max_batch * 8); if (r__) { mmc_backbone_destroy(bb); return r__; } }
     { const char* e = getenv("MMC_TAIL_CLK");
       if (e && e[0] == '1' && !bb->keep) {
-          int r__ = dev_alloc(bb, &bb->tail_clk, (size_t)max_batch * 64); if (r__) { mmc_backbone_destroy(bb); return r__; }
-          hipMemset(bb->tail_clk, 0, (size_t)max_batch * 64 * sizeof(float));
-          r__ = dev_alloc(bb, &bb->mid_clk, (size_t)max_batch * 128); if (r__) { mmc_backbone_destroy(bb); return r__; }
-          hipMemset(bb->mid_clk, 0, (size_t)max_batch * 128 * sizeof(float));
+          // rows are indexed lane * lane_cap + row with lane_cap = ceil(max_batch / lanes): up to lanes - 1 <= 3 rows more than max_batch
+          const size_t clk_rows = (size_t)max_batch + 4;
+          int r__ = dev_alloc(bb, &bb->tail_clk, clk_rows * 64); if (r__) { mmc_backbone_destroy(bb); return r__; }
+          hipMemset(bb->tail_clk, 0, clk_rows * 64 * sizeof(float));
+          r__ = dev_alloc(bb, &bb->mid_clk, clk_rows * 128); if (r__) { mmc_backbone_destroy(bb); return r__; }
+          hipMemset(bb->mid_clk, 0, clk_rows * 128 * sizeof(float));
           bb->use_graph = false;
       } }
     std::vector<uint64_t> table(2 * (size_t)nt);
@@ -683,15 +689,6 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     for (int k = 0; k < 32; ++k) wf[((k / 8) * 16 + c) * 8 + (k % 8)] = (_Float16)(float)(w[(size_t)c * 32 + k] * (1.0 / LOG2E));
                 TRY_OR_FREE(dev_upload(bb, &bb->b0_pre_w, wf));
             }
-            if (i == 2 && is_b0 && fuse_enabled && B.ce == 144 && B.d.cout == 24) {
-                // block 2's project conv as MFMA A fragments for mb3_kernel: [n tile][k-step][lane (row m, quarter q)][8]
-                std::vector<_Float16> wf((size_t)2 * 5 * 64 * 8, (_Float16)0.0f);
-                for (int n = 0; n < 24; ++n)
-                    for (int k = 0; k < 144; ++k)
-                        wf[((((size_t)(n / 16) * 5 + k / 32) * 64) + ((k % 32) / 8) * 16 + (n % 16)) * 8 + (k % 8)] =
-                            (_Float16)(float)(w[(size_t)n * 144 + k] * (1.0 / LOG2E));
-                TRY_OR_FREE(dev_upload(bb, &bb->b2_pre_w, wf));
-            }
             if ((projse_enabled && i >= 3 && i <= 10) ||
                 (fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
                  proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0))) {
@@ -782,18 +779,6 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                                 for (int j = 0; j < 4; ++j) wq[(size_t)c * 32 + 8 * qq + j] = wn[(size_t)c * kp + 4 * qq + j];
                         TRY_OR_FREE(dev_upload(bb, &bb->b1_exp_pre, wq));
                     }
-                    if (i == 3 && is_b0 && B.d.cin == 24 && B.ce == 144 && kp == 32) {
-                        // mb3_kernel's expand B fragments: lane (n, q) holds K slots 8q .. 8q+7 = input channels 4q .. 4q+3 and
-                        // 16+4q .. 16+4q+3 (q < 2; zeros otherwise) -- the layout block 2's in-kernel project leaves in the lanes
-                        std::vector<_Float16> wq((size_t)9 * 64 * 8, (_Float16)0.0f);
-                        for (int c = 0; c < B.ce; ++c)
-                            for (int qq = 0; qq < 4; ++qq)
-                                for (int j = 0; j < 8; ++j) {
-                                    const int ch = j < 4 ? 4 * qq + j : (qq < 2 ? 16 + 4 * qq + (j - 4) : -1);
-                                    if (ch >= 0) wq[(((size_t)(c / 16) * 64) + qq * 16 + (c % 16)) * 8 + j] = wn[(size_t)c * kp + ch];
-                                }
-                        TRY_OR_FREE(dev_upload(bb, &bb->b3_exp_pre, wq));
-                    }
                     {   // fragment order: ((c/16 * ksteps + k/32) * 64 + (k%32)/8 * 16 + c%16) * 8 + k%8
                         std::vector<_Float16> wf((size_t)B.ce * kp, (_Float16)0.0f);
                         for (int c = 0; c < B.ce; ++c)
@@ -879,15 +864,6 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
         { const char* m1 = getenv("MMC_MB1"); bb->mb1 = !(m1 && m1[0] == '0'); }
         bb->fuse_b0b1 = !(e && e[0] == '0') && bb->fuse_stem && bb->b0_pre_w && bb->b1_exp_pre && B1.fused && !B1.use_d && B1.f_TH == 8 &&
                         B1.f_TWo == 8 && B1.f_CC == 48 && B1.f_tw == 2 && B1.f_pb == 1 && !B1.f_wlds && B1.f_npair == 3;
-    }
-    {
-        const char* e = getenv("MMC_FUSE_B2");
-        const BlockW &B2 = bb->blk[2], &B3 = bb->blk[3];
-        // opt-in (MMC_FUSE_B2=1): measured 120 us per 128 patches against 44 + 45 for pw_gemm + mbt2 -- see DESIGN.md section 4
-        bb->fuse_b2b3 = (e && e[0] == '1') && !bb->keep && bb->b2_pre_w && bb->b3_exp_pre && bb->mbt && bb->mbt2 && bb->se_small && B2.se_wr_nat &&
-                        B2.fused && B3.fused && B2.t_dwp && B3.t_dwp && B2.skip && B2.H == 56 && B3.H == 56 && B3.d.k == 5 && B3.d.s == 2 &&
-                        B2.project.nt == 2 && B2.project.n_chunks == 1;
-        if (bb->fuse_b2b3 && (size_t)56 * 56 * 144 > max_exp) max_exp = (size_t)56 * 56 * 144;   // block 2's depthwise output parks in expbuf
     }
     if (rd.next != nt) {
         mmc_backbone_destroy(bb);
@@ -1011,7 +987,6 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
     const bool se_small_enabled = bb->se_small;
     const int FEAT = bb->feat;
     (void)FEAT;
-    bool b2_parked = false;   // block 2's depthwise output sits in expbuf and its project runs inside block 3's kernel (mb3_kernel)
     for (int i = 0; i < bb->nblk; ++i) {
         if (i == 12 && bb->tail_tab) {
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
@@ -1045,9 +1020,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         BlockW& B = bb->blk[i];
         const int HWi = B.H * B.H, HWo = B.Ho * B.Ho;
         int nparts = B.parts;
-        // small-K, small-N project on a big image: thin_proj_kernel (5-6 k-steps measured slower than pw_gemm: 48.7 vs 43.8 us on B0's b2)
-        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); return e ? atoi(e) : 5; }();
-        const bool use_thin = bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && B.project.Kp / 32 <= thin_max && B.project.N <= 32 &&
+        // small-K, small-N project on a big image: thin_proj_kernel (up to 5 k-steps since the gate is folded into the weight
+        // fragments: B0's b2 30.8 vs 43.7 us on pw_gemm; MMC_THIN_PROJ_KS moves the limit, clamped to what is instantiated, and a
+        // shape without an instantiation stays on pw_gemm)
+        static const int thin_max = [] { const char* e = getenv("MMC_THIN_PROJ_KS"); const int v = e ? atoi(e) : 5; return v < 0 ? 0 : (v > 6 ? 6 : v); }();
+        const bool use_thin = bb->thin_proj && B.project.nt == 2 && B.project.n_chunks == 1 && B.project.Kp / 32 <= thin_max &&
+                              thin_proj_has(B.project.Kp / 32) && B.project.N <= 32 &&
                               (B.project.N & 7) == 0 && (HWo & 15) == 0 && HWo >= 3136;
         // block 1's depthwise output as three 32-channel planes between mb1_kernel and thin_proj_kernel (see mb1_kernel); per-tensor
         // mode keeps the interleaved tensor it hands out (MMC_B1_PLANAR=0 switches the planes off)
@@ -1082,18 +1060,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char ml[48];   // the instantiation's template arguments, as rocprofv3 names it
             snprintf(ml, sizeof ml, "%s<%d,%d,%d,%d>", B.d.s == 2 ? "mbt2" : "mbt", B.d.k, (B.d.cin + 31) / 32, B.ce, B.H);
-            if (i == 3 && b2_parked) {
-                // x is still block 2's input (its skip operand); block 2's gate is in ws.gate
-                Mb3Args m3{};
-                m3.D2 = ws.expbuf; m3.pre_w = bb->b2_pre_w; m3.pre_b = bb->blk[2].project.b; m3.pre_gate = ws.gate; m3.pre_res = x;
-                m3.wexp = bb->b3_exp_pre; m3.bexp = B.expand.b; m3.dwp = B.t_dwp; m3.bdw = B.dw_b; m3.D = ws.dwbuf; m3.pool = ws.pool_part; m3.B = n;
-                snprintf(nm, sizeof nm, "b2.project+b3.mbconv");
-                STEP(nm, "mb3", launch_mb3(m3, st));
-                b2_parked = false;
-            } else {
-                if (i == 2 && bb->fuse_b2b3) { ta.D = ws.expbuf; b2_parked = true; }
-                STEP(nm, ml, launch_mbt(ta, st));
-            }
+            STEP(nm, ml, launch_mbt(ta, st));
         } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
             Mid14Args ma{};
             ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp4; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
@@ -1223,7 +1190,6 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
                                             ws.gate, st));
         if (bb->keep) { int r = save_act(bb, nm, ws.gate, (size_t)n * B.ce, false, st); if (r) return r; }
         if (i == 0 && bb->fuse_b0b1 && stem_fused) continue;   // block 0's project runs inside block 1's kernel
-        if (i == 2 && b2_parked) continue;                     // block 2's inside block 3's (x stays block 2's input)
         snprintf(nm, sizeof nm, "b%d.project", i);
         const int pks = B.project.Kp / 32;
         if (use_thin) {
@@ -1311,6 +1277,9 @@ static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hi
             return 0;
         }
     }
+    if (bb->evictions >= MMC_GRAPH_CACHE) return forward_pass(bb, pin, n, pout, st, nullptr);   // cache frozen: see `evicted`
+    for (auto& k : bb->evicted)
+        if (k.in == pin && k.out == pout && k.n == n) return forward_pass(bb, pin, n, pout, st, nullptr);
     bool repeat = false;
     for (auto& k : bb->seen) repeat = repeat || (k.in == pin && k.out == pout && k.n == n);
     if (!repeat) {
@@ -1338,14 +1307,32 @@ static int run_pass(mmc_backbone* bb, const uint8_t* pin, int n, float* pout, hi
         return forward_pass(bb, pin, n, pout, st, nullptr);
     }
     if (bb->graphs.size() >= MMC_GRAPH_CACHE) {
-        // least recently used graph goes; it may still be executing on a stream this handle was given earlier
-        HIP_TRY(hipDeviceSynchronize());
-        hipGraphExecDestroy(bb->graphs.front().exec);
+        // least recently used graph goes; it may still be executing on a stream this handle was given earlier: passes of a
+        // handle are serialised (PassOrder), so waiting for the last pass's completion event covers every earlier replay
+        if (bb->have_last && hipEventSynchronize(bb->last_done) != hipSuccess) {
+            (void)hipGetLastError();
+            hipGraphExecDestroy(exec);
+            return forward_pass(bb, pin, n, pout, st, nullptr);
+        }
+        const mmc_backbone::GraphEntry old = bb->graphs.front();
+        hipGraphExecDestroy(old.exec);
         bb->graphs.erase(bb->graphs.begin());
+        if (bb->evicted.size() >= 8 * MMC_GRAPH_CACHE) bb->evicted.erase(bb->evicted.begin());
+        bb->evicted.push_back({old.in, old.out, old.n});
+        ++bb->evictions;
     }
     bb->graphs.push_back({pin, pout, n, exec});
+    ++bb->captures;
     HIP_TRY(hipGraphLaunch(exec, st));
     return 0;
+}
+
+extern "C" int mmc_backbone_graph_stats(mmc_backbone* bb, int64_t stats[3])
+{
+    if (!bb || !stats) return fail(MMC_ERR_ARG, "backbone handle / stats is NULL");
+    std::lock_guard<std::mutex> lock(bb->mu);
+    stats[0] = bb->captures; stats[1] = bb->evictions; stats[2] = (int64_t)bb->graphs.size();
+    return MMC_OK;
 }
 
 extern "C" int mmc_backbone_extract(mmc_backbone* bb, const void* patches, int64_t n, float* out_features,

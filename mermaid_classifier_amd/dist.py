@@ -38,32 +38,57 @@ def chunk_items(items, n_chunks: int):
     return [c for c in chunks if c]
 
 
+class FeatureGatherer:
+    """The all-gather of one rank block per rank, with every buffer allocated ONCE: the padded send block (ragged shards
+    only) and the (world * per, D) receive matrix.  `gather(local)` issues one all_gather_into_tensor and returns the
+    (n_total, D) matrix in global patch order -- a view of the receive buffer when the shards are even, otherwise one
+    torch.cat of the valid rows.  `gather(local, async_op=True)` returns (work, finish): wait on `work`, then call
+    `finish()` for the matrix (the collective runs beside whatever the caller launches meanwhile).
+    BASELINE configs[3] is exactly one such call per rank: 1 M patches -> one gather of (125 000, 1280) blocks."""
+
+    def __init__(self, n_total: int, d: int, like, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total, self.d = int(n_total), int(d)
+        self.lo, self.hi = shard_range(self.n_total, self.rank, self.world)
+        self.per = -(-self.n_total // self.world) if self.n_total else 0
+        self.sizes = [shard_range(self.n_total, r, self.world) for r in range(self.world)]
+        self.even = self.n_total % self.world == 0
+        self.out = like.new_empty((self.world * self.per, self.d))
+        self.padded = None if (self.hi - self.lo) == self.per else like.new_zeros((self.per, self.d))
+
+    def _finish(self):
+        import torch
+        if self.even:
+            return self.out
+        return torch.cat([self.out[r * self.per: r * self.per + (b - a)] for r, (a, b) in enumerate(self.sizes)], dim=0)
+
+    def gather(self, local, async_op: bool = False):
+        import torch.distributed as dist
+        if local.dim() != 2 or tuple(local.shape) != (self.hi - self.lo, self.d):
+            raise ValueError(f"rank {self.rank} holds {tuple(local.shape)}, expected ({self.hi - self.lo}, {self.d})")
+        if self.per == 0:
+            return (None, lambda: local.new_zeros((0, self.d))) if async_op else local.new_zeros((0, self.d))
+        send = local
+        if self.padded is not None:
+            self.padded[: local.shape[0]].copy_(local)
+            send = self.padded
+        work = dist.all_gather_into_tensor(self.out, send.contiguous(), group=self.group, async_op=async_op)
+        if async_op:
+            return work, self._finish
+        return self._finish()
+
+
 def gather_features(local, n_total: int, group=None):
     """All-gather ragged (n_local, D) blocks into the (n_total, D) matrix, rows in global patch order.
     `local` is a torch tensor (cuda for nccl/RCCL, cpu for gloo).  Blocks are padded to the largest
-    shard so a single all_gather_into_tensor moves them; padding rows are dropped afterwards."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    lo, hi = shard_range(n_total, rank, world)
-    if local.dim() != 2 or local.shape[0] != hi - lo:
-        raise ValueError(f"rank {rank} holds {tuple(local.shape)}, expected ({hi - lo}, D)")
-    d = local.shape[1]
-    per = -(-n_total // world) if n_total else 0
-    if per == 0:
-        return local.new_zeros((0, d))
-    padded = local
-    if local.shape[0] != per:
-        padded = local.new_zeros((per, d))
-        padded[: local.shape[0]] = local
-    out = local.new_empty((world * per, d))
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
-    if n_total % world == 0:
-        return out
-    rows = [out[r * per: r * per + (shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0])] for r in range(world)]
-    return torch.cat(rows, dim=0)
+    shard so a single all_gather_into_tensor moves them; padding rows are dropped afterwards.
+    One-shot form (allocates its buffers): a loop that gathers repeatedly keeps a FeatureGatherer."""
+    if local.dim() != 2:
+        raise ValueError(f"expected an (n_local, D) block, got {tuple(local.shape)}")
+    return FeatureGatherer(n_total, local.shape[1], local, group=group).gather(local)
 
 
 def extract_sharded(extract_fn: Callable, patches, group=None):

@@ -48,10 +48,6 @@ def b0_launches(batch: int) -> List[Launch]:
             # shows up as PMC traffic above this figure)
             out.append(Launch("b0.project+b1.mbconv", "mbconv", m_in * 32 * 2 + m_out * ce * 2 + ce * cin * 2 + k * k * ce * 4,
                               2 * m_in * cin * ce + 2 * m_out * ce * k * k + 2 * 2 * m_in * 32 * 16))
-        if i == 3:   # block 3's fused kernel with block 2's SE scale + project conv + skip folded in (mb3_kernel): reads block 2's
-            # depthwise output (144 channels) and its skip input (24), writes block 3's depthwise output; block 2's output never moves
-            out.append(Launch("b2.project+b3.mbconv", "mbconv", m_in * (144 + 24) * 2 + m_out * ce * 2 + ce * cin * 2 + k * k * ce * 4 + 24 * 144 * 2,
-                              2 * m_in * cin * ce + 2 * m_out * ce * k * k + 2 * m_in * 144 * 24))
         if 3 <= i <= 10:   # squeeze-excite + project in one launch (proj_patch_kernel): no gate tensor in HBM
             out.append(Launch(f"b{i}.projse", "projse", m_out * (ce + cout) * 2 + res + batch * ce * 4 + cout * ce * 2 + 2 * cs * ce * 2,
                               2 * m_out * ce * cout + 2 * batch * 2 * cs * ce))

@@ -9,6 +9,15 @@ lookup, the shuffle order (numpy ``default_rng(random_state)``, :139-157), Gloro
 under ``torch.manual_seed(random_state)``, so equal seeds give equal initial weights, :176-184), softmax + float64
 renormalisation of ``_forward_probs`` (:332-376).  Forward, weighted cross-entropy, L2 term, backward and Adam run in
 ``libmermaid_mi355.so`` (``mmc_trainer_*``, csrc/trainer.hip).  No CPU fallback.
+
+Taken as they are from the reference (the sklearn-protocol shell a drop-in has to reproduce; argument checks, defaults
+and error strings included): ``__init__`` (:95-136, the argument validation and attribute names), ``_resolve_batch_size``
+(:138-141), ``_seed_rng`` (:143-157), ``_labels_to_indices`` (:159-173), ``_build_class_weight_vector`` (the reference's
+``_build_class_weight_tensor``, :192-214, minus the tensor construction), ``get_params`` / ``set_params`` (:380-408) and the input checks at the top of ``partial_fit`` /
+``_forward_probs``.  Written here, with no counterpart there: ``_initial_parameters`` (host Glorot draw handed to the
+device), ``_create_trainer``, the device half of ``partial_fit`` (``mmc_trainer_partial_fit_ordered``), ``_forward_probs``'s
+logits call (``mmc_trainer_logits``), ``parameters`` / ``_module`` / ``_adam_state`` (state read back through the C ABI),
+``__getstate__`` / ``__setstate__`` (the pickle carries host copies of weights and Adam moments), ``_release``.
 """
 
 from __future__ import annotations

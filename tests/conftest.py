@@ -71,8 +71,11 @@ def cosine(a, b):
 #   dp   = max over rows and classes of |p_hip - p_ref|: what the (fp16-tolerance) feature error does to the probabilities,
 #          measured in this run and itself bounded by `dp_bound`;
 #   a row whose reference top-2 margin exceeds 2*dp cannot flip, and must not;
-#   a row inside that band may flip, but only to the reference's runner-up, and at most `max_flip_frac` of all rows do.
-def check_labels(p_got, p_ref, dp_bound, max_flip_frac, what=""):
+#   a row inside that band may flip, but only to the reference's runner-up, and at most `max_flips` rows do.  Measured on
+#   MI355X (rounds 1-2, every call site: 12 / 75 / 50 oracle-checked rows): 0 mismatches, 0-1 rows inside the band.  The gate is
+#   therefore what is observed (0) plus a margin of ONE row -- and only when a row sits inside the band at all: two flips, or one
+#   flip with an empty band, fail.
+def check_labels(p_got, p_ref, dp_bound, max_flips=1, what=""):
     p_got, p_ref = np.asarray(p_got, np.float64), np.asarray(p_ref, np.float64)
     a_got, a_ref = p_got.argmax(1), p_ref.argmax(1)
     order = np.argsort(p_ref, 1)
@@ -86,5 +89,5 @@ def check_labels(p_got, p_ref, dp_bound, max_flip_frac, what=""):
     assert dp <= dp_bound
     assert not np.any(flips & ~band)                                 # decidable rows: identical labels
     assert np.all(a_got[flips] == order[flips, -2])                  # a flip lands on the reference's runner-up
-    assert flips.sum() <= max_flip_frac * len(a_ref)
+    assert flips.sum() <= min(max_flips, int(band.sum()))
     return int(flips.sum()), int(band.sum()), dp

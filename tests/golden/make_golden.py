@@ -81,6 +81,32 @@ def backbone_b4():
     print("b4 fixtures written")
 
 
+def strip_debug_pkl(path: Path) -> int:
+    """Drop the `*.debug_pkl` members torch.jit.save adds to a TorchScript archive.  They hold the source ranges -- and with
+    them the TEXT -- of the scripted module's Python source (here the reference's inference/head.py), which must not travel
+    with the fixtures; torch.jit.load does not need them (it only loses file:line in error messages).  The other members are
+    copied as they are: STORED, data records padded to 64-byte offsets like torch's own writer does.  Returns members removed."""
+    import zipfile
+    src = zipfile.ZipFile(path)
+    infos = src.infolist()
+    keep = [i for i in infos if not i.filename.endswith(".debug_pkl")]
+    if len(keep) == len(infos):
+        return 0
+    tmp = Path(str(path) + ".tmp")
+    with zipfile.ZipFile(tmp, "w", compression=zipfile.ZIP_STORED) as dst:
+        for i in keep:
+            zi = zipfile.ZipInfo(i.filename, date_time=(1980, 1, 1, 0, 0, 0))
+            zi.compress_type = zipfile.ZIP_STORED
+            # pad the local header's extra field so the payload starts on a 64-byte boundary (what PyTorchStreamWriter does)
+            base = dst.fp.tell() + 30 + len(i.filename.encode())
+            pad = (-(base + 4)) % 64
+            zi.extra = b"FB" + pad.to_bytes(2, "little") + b"Z" * pad
+            dst.writestr(zi, src.read(i.filename))
+    src.close()
+    tmp.replace(path)
+    return len(infos) - len(keep)
+
+
 def head():
     sys.path.insert(0, "/root/reference")
     sys.path.insert(0, "/root/reference/tests")
@@ -98,6 +124,7 @@ def head():
         h.eval()
         frozen = torch.jit.freeze(torch.jit.script(h))
         torch.jit.save(frozen, str(out_dir / "model.pt"))
+        strip_debug_pkl(out_dir / "model.pt")     # no reference source text inside the fixture
         manifest = {
             "schema_version": SCHEMA_VERSION, "task": TASK_NAME,
             "classes": model.classes_.tolist(), "input_dim": int(input_dim),
@@ -200,3 +227,6 @@ if __name__ == "__main__":
         head()
     if "trainer" in which:
         trainer()
+    if "strip" in which:      # post-process archives that were written before strip_debug_pkl existed
+        for pt in sorted(HERE.glob("*/model.pt")):
+            print(pt, "removed", strip_debug_pkl(pt), "debug_pkl member(s)")

@@ -96,6 +96,72 @@ def test_bench_launches_its_own_ranks_from_a_plain_invocation():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["gather_ok"] is True and out["value"] is None
     assert out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    # configs[3]: ONE gather of the rank's whole block (all K steps' rows) by default, and the line says so
+    cfg = out["config"]
+    assert cfg["gather_every_steps"] == 3 and cfg["gathers_per_run"] == 1 and cfg["gather_overlap"] is False
+    assert "1 RCCL all-gather of (15, 8)" in cfg["workload"]
+
+
+def test_bench_gathers_once_per_group_with_a_ragged_last_group():
+    """--gather-every 2 over 5 steps: groups of 2, 2 and 1 steps (ragged K), gathered asynchronously behind the next group; the
+    dry run checks every gathered matrix for global row order (ragged shards inside each group as well)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "0", "--gather-every", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    cfg = out["config"]
+    assert out["gather_ok"] is True and cfg["gather_every_steps"] == 2 and cfg["gathers_per_run"] == 3 and cfg["gather_overlap"] is True
+    r = _run_bench(["--gpus", "2", "--dry-run", "--steps", "5", "--warmup", "0", "--gather-every", "2"], {"MMC_BENCH_OVERLAP": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["config"]["gather_overlap"] is False
+
+
+def _gatherer_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mermaid_classifier_amd.dist import FeatureGatherer, shard_range
+        res = []
+        for n_total in (8, 7):                      # even and ragged shards; the SAME gatherer is reused three times
+            lo, hi = shard_range(n_total, rank, world)
+            g = FeatureGatherer(n_total, 4, torch.zeros(1))
+            ptr = g.out.data_ptr()
+            for it in range(3):
+                local = (torch.arange(lo, hi, dtype=torch.float32) + 100 * it).view(-1, 1).repeat(1, 4)
+                if it == 1:
+                    work, fin = g.gather(local, async_op=True)
+                    work.wait()
+                    full = fin()
+                else:
+                    full = g.gather(local)
+                res.append((n_total, it, full[:, 0].clone().numpy(), g.out.data_ptr() == ptr))
+            try:
+                g.gather(torch.zeros((hi - lo + 1, 4)))
+                res.append("no error")
+            except ValueError:
+                pass
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_feature_gatherer_reuses_its_buffers_and_keeps_patch_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert "no error" not in res
+        for n_total, it, col, same_buf in res:
+            np.testing.assert_array_equal(col, np.arange(n_total) + 100 * it)
+            assert same_buf          # no allocation per call
 
 
 def test_bench_self_launch_fails_when_a_rank_dies():

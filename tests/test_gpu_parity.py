@@ -76,9 +76,15 @@ def test_b4_backbone_matches_oracle(synth_sd_b4):
                 emu = net.extract_features(ref.transformation(patches), emulate_fp16=True).numpy()
             r, e, c = rel_l2(got, want), rel_l2(emu, want), cosine(got, want)
             print(f"b4 {kind} rel-L2 {r} (fp16-storage emulation {e}) cos {c}")
-            assert got.shape == (4, 1792) and np.all(r < np.maximum(tol, 2 * e))
-            # the reference's cosine gate: every white-noise patch (its own gate inputs), every well-conditioned image-like one
-            assert np.all(c[(e < tol) | (kind == "noise")] >= COS_GATE) and (kind == "noise" or (e < tol).sum() >= 3)
+            assert got.shape == (4, 1792)
+            # explicit per-row expectations (a second bad row fails): image-like rows 0, 1, 3 meet the gate outright; row 2 -- and
+            # the four white-noise rows -- are the inputs on which the oracle's own fp16-storage emulation misses it (1.08e-2;
+            # 2e-2), and must stay within twice that emulation's error
+            if kind == "natural":
+                assert np.all(e[[0, 1, 3]] < tol) and np.all(r[[0, 1, 3]] < tol), (r, e)
+                assert r[2] <= 2 * e[2] and np.all(c[[0, 1, 3]] >= COS_GATE), (r, e, c)
+            else:
+                assert np.all(r <= np.maximum(tol, 2 * e)) and np.all(c >= COS_GATE), (r, e, c)   # the reference's own cosine gate
         both = bb.extract(np.concatenate([nat, noi]))      # 8 > max_batch: internal chunking
         assert np.array_equal(both, np.concatenate(outs))
     finally:
@@ -110,7 +116,9 @@ def test_b4_at_config_batch_size(synth_sd_b4):
         assert np.array_equal(bb.extract(p), f)
         r = rel_l2(f[:4], g["natural4"])
         print("b4 @512 natural rel-L2", r, "noise cos", cosine(f[4:8], g["noise4"]))
-        assert np.sort(r)[2] < TOL_NATURAL                  # (patch 2 is the ill-conditioned one, see test_b4_backbone_matches_oracle)
+        # per-row, as in test_b4_backbone_matches_oracle: rows 0, 1, 3 meet the gate; row 2 (fp16-storage emulation 1.08e-2,
+        # DESIGN.md "Numerics") stays within twice the emulated error
+        assert np.all(r[[0, 1, 3]] < TOL_NATURAL) and r[2] <= 2 * 1.08e-2, r
         assert cosine(f[4:8], g["noise4"]).min() >= COS_GATE
     finally:
         bb.close()
@@ -284,7 +292,7 @@ def test_extract_then_classify_labels_match_oracle_chain(backbone, oracle_net):
     got = pred.predict_proba(f_hip)
     # every row is accounted for (conftest.check_labels): identical wherever the reference's top-2 margin exceeds twice the
     # measured probability perturbation; flips inside that band are counted, must land on the runner-up, and are bounded
-    check_labels(got, want, dp_bound=2e-4, max_flip_frac=0.10, what="12 image-like patches, head108")
+    check_labels(got, want, dp_bound=2e-4, max_flips=1, what="12 image-like patches, head108")
     # same features in -> identical labels, always
     assert np.array_equal(pred.predict_proba(f_ref).argmax(1), want.argmax(1))
 
@@ -340,7 +348,7 @@ def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone
     bb.close()
 
 
-@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_B11", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MID14_B11=1", "MMC_MID14M=1", "MMC_MB1", "MMC_MBT", "MMC_MBT2", "MMC_THIN_PROJ", "MMC_B1_PLANAR", "MMC_FUSE_B2=1", "MMC_GRAPH",
+@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_B11", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MID14_B11=1", "MMC_MID14M=1", "MMC_MB1", "MMC_MBT", "MMC_MBT2", "MMC_THIN_PROJ", "MMC_B1_PLANAR", "MMC_GRAPH",
                                   "MMC_LANES"])
 def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_backbone, knob, monkeypatch):
     """Each fusion has an environment switch (the separate kernels stay in the library as the reference
@@ -442,6 +450,19 @@ def test_graph_cache_eviction_and_stream_switches_keep_results(checkpoint_path):
                 with torch.cuda.stream(streams[(i + rep) & 1]):
                     bb.extract(p, out=o)
         torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, want.roll(i % 6, 0)), i
+        # Cost, not only results: a caller that cycles through more combinations than the cache holds must not pay a capture
+        # per call.  A combination whose graph was evicted is never captured again, and after one turnover of the cache
+        # (32 evictions) nothing new is captured: the counters stop moving however many more rounds are run.
+        st0 = bb.graph_stats()
+        assert st0["cached"] <= 32 and st0["captures"] <= 32 + 32
+        for rep in range(3):
+            for i, (p, o) in enumerate(zip(bufs, outs)):
+                bb.extract(p, out=o)
+        torch.cuda.synchronize()
+        st1 = bb.graph_stats()
+        assert st1["captures"] <= 32 + 32 and st1["evictions"] <= 32, (st0, st1)
         for i, o in enumerate(outs):
             assert torch.equal(o, want.roll(i % 6, 0)), i
     finally:

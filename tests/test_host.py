@@ -291,3 +291,19 @@ def test_numerics_gate_runs_as_the_reference_calls_it(checkpoint_path, oracle_ne
         cls(data_locations={"weights": loc}, device="cpu", batch_size=3)
     with pytest.raises(RuntimeError, match="needs pyspacer"):
         verify_device_numerics(object(), loc, 4, "cuda")
+
+
+def test_golden_torchscript_archives_carry_no_reference_source_text():
+    """tests/golden/*/model.pt are fixtures (the artifact contract itself).  torch.jit.save also writes `*.debug_pkl` members
+    holding the scripted module's Python source text (the reference's inference/head.py) and its path; make_golden.py strips
+    them (strip_debug_pkl) -- reference source must not travel.  The archives still load (tests that use them do)."""
+    import zipfile
+    from pathlib import Path
+    pts = sorted((Path(__file__).resolve().parent / "golden").glob("*/model.pt"))
+    assert len(pts) >= 2
+    for pt in pts:
+        z = zipfile.ZipFile(pt)
+        names = z.namelist()
+        assert not [n for n in names if n.endswith(".debug_pkl")], pt
+        for n in names:
+            assert b"/root/reference" not in z.read(n), (pt, n)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel SQ / TCC / TCP counter table from the PMC passes of tools/gpu_counters.sh.
+"""Per-kernel SQ / TCC / TCP counter table from the PMC passes of tools/gpu.sh counters.
 
   python tools/summarize_counters.py <round-tag> <dir with sq1/ sq2/ tcc/ fetch/ write/> [title suffix]
 
@@ -63,7 +63,7 @@ def main():
     kernels = [k for k in kernels if passes["sq1"][2][k][0] > 0 and "rocclr" not in k and val("sq1", k, "SQ_WAVES") > 0]
     out = [f"# SQ / TCC / TCP counters per kernel launch ({tag}{suffix})", "",
            "command per pass: `rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-           "--no-cpu-baseline --profile-passes 1` (tools/gpu_counters.sh; one counter group per run; every launch covers one "
+           "--no-cpu-baseline --profile-passes 1` (tools/gpu.sh counters; one counter group per run; every launch covers one "
            "lane = 128 patches; kernels are serialised by the profiler, so durations are those of a kernel alone on the chip)", "",
            "Groups: sq1 = SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY "
            "SQ_INSTS_VALU; sq2 = SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES "
