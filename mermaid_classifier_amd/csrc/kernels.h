@@ -151,7 +151,7 @@ struct Mid14Args {
     int nsplit;               // workgroups per patch (each takes every nsplit-th chunk of 96 channels)
     int stride;               // 1, or 2 (block 11: D is [B][49][Ce])
     float* dbg_clk;           // optional [B][8 workgroups][16]: shader cycles of the first chunk's phases (MMC_TAIL_CLK=1)
-    const _Float16* dwdiag;   // optional [Ce/16][NT][64][8]: block-diagonal depthwise fragments (NT = 13 for 5x5, 5 for 3x3) -> mid14m_kernel
+    const _Float16* dwdiag;   // optional [Ce/16][ks][2][64][4]: Toeplitz depthwise fragments of v_mfma_f32_4x4x4_16B_f16 -> mid14m_kernel
 };
 int launch_mid14(const Mid14Args& a, hipStream_t st);
 

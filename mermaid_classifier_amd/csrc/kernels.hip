@@ -2938,226 +2938,263 @@ __global__ __launch_bounds__(512) void mid14_kernel(Mid14Args a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// mid14m_kernel: the front half of a 14x14 MBConv block with the DEPTHWISE CONV ON THE MATRIX PIPE.
+// mid14m_kernel: the front half of a 14x14 MBConv block with the DEPTHWISE CONV ON THE MATRIX PIPE (round 3: 4x4x4 form).
 //
-// Round 2's counters and phase clocks say the fused expand + depthwise kernels are bound by vector-instruction issue: per
-// output a 5x5 depthwise costs 15 v_dot2c (12.5 in theory) + 4 SiLU instructions + conversion / store / bookkeeping, the two
-// waves of a SIMD share one vector port, and the matrix pipe idles at 2-9 %.  A depthwise conv is a GEMM with a
-// block-diagonal weight matrix:  Y[c][p] = sum_t W[t][c] X[p + t][c]  =  sum_k A[c][k] B[k][p]  with k = (tap t, channel c'),
-// A[c][(t, c')] = W[t][c] * (c' == c),  B[(t, c')][p] = X[p + t][c'].  One v_mfma_f32_16x16x32_f16 takes a 16-channel group,
-// 16 pixels and TWO taps (k = 2 taps x 16 channels): 512 useful MACs of its 8192, i.e. 32 MAC/clk/SIMD -- the ideal rate of
-// v_dot2c (measured: 21.7) -- on a pipe that has nothing else to do, and the vector port is left with SiLU + pack + store
-// (~6 instructions per output instead of ~21).  The B operand is a plain 16-byte LDS read of pixel p + t, channels 8h .. 8h+7:
-// the expanded tensor is kept in [pixel slot][16 channels] rows on a zero-bordered 18 x 18 grid, so taps outside the image
-// read zeros and nothing is predicated.  The block-diagonal A fragments (one nonzero per lane row) are packed on the host
-// (`dwdiag`, 1 KB per channel group and tap pair: 13 for 5x5, 5 for 3x3).
+// The fused expand + depthwise kernels are bound by vector-instruction issue (per output a 5x5 depthwise costs 15 v_dot2c + 4
+// SiLU instructions + conversion / store / bookkeeping) while the matrix pipe idles at 2-9 %.  Round 2 put the depthwise conv
+// on v_mfma_f32_16x16x32_f16 with a block-diagonal weight matrix: 1/16 of every MFMA useful, 13 LDS fragments of 1 KB per output
+// row -- equal in speed.  v_mfma_f32_4x4x4_16B_f16 multiplies 16 INDEPENDENT 4x4x4 blocks, so a block can be a channel with its
+// own weights (tools/ubench/mfma4x4.hip: layout confirmed, 8.4 cycles per instruction, one vector instruction of a SIMD-mate wave
+// rides along):
+//     block = channel c;  D[i][j] = out[c][y0 + j][x0 + i]   (4 output columns x 4 output rows)
+//     B[k][j] = in[c][y0 + j + ky - R][xq + k]               (a lane's four k values are 8 contiguous bytes of a planar row)
+//     A[i][k] = w[c][ky][xq + k - (x0 + i) + R]              (a Toeplitz slice of kernel row ky; zero outside 0 .. KS-1)
+// with the input quads xq = x0 - 2 and x0 + 2: two MFMAs per (kernel row, 4x4 output tile), 20 of their 32 products per output
+// useful (5x5).  A 16-channel group's 196 outputs take 4 x 4 tiles x KS rows x 2 = 160 MFMAs (144: the last column tile's
+// second quad lies in the zero border) = 1.2 k matrix-pipe cycles against ~3.7 k vector-issue cycles of v_dot2c, read 80 x 512 B
+// of LDS (block-diagonal form: 182 x 1 KB), and the vector port keeps SiLU + pack only.  The Toeplitz fragments (A) are packed on
+// the host (`dwtoe`: 8 bytes per lane, kernel row and quad), loaded once per channel group.
 //
-// Work split: a WAVE owns whole 16-channel groups -- it expands its group for all 196 pixels (swapped MFMA: a lane gets 4
-// consecutive channels of one pixel) into its PRIVATE [326 slots][16] LDS region, runs the depthwise MFMAs over it, applies
-// SiLU, stores the depthwise output and reduces the pool sums in registers.  No data crosses waves after the block input has
-// been staged in LDS: ONE barrier per kernel, no lockstep, the two waves of a SIMD overlap one's MFMAs with the other's SiLUs.
-// Tap pairs: (ky, kx) with (ky + 1, kx) for ky = 0, 2 (and ky = 0 for 3x3) -- second tap 18 slots on; the last kernel row pairs
-// (kx, kx + 1) -- second tap one slot on; the odd tap is paired with a zero weight.  Two lane addresses (vertical / horizontal
-// pairs) + immediate offsets address every B fragment.
+// Work split (as in round 2): a WAVE owns whole 16-channel groups -- it expands its group for all 196 pixels (un-swapped MFMA:
+// a lane gets 4 consecutive pixels of one channel) into its PRIVATE planar region E[16 channels][18 rows][20 columns] (two zero
+// border rows / columns on every side: nothing is predicated), runs the depthwise MFMAs over it, applies SiLU, transposes a
+// 4-row strip through a private [56 pixels][16 channels] tile and stores it to D with 16-byte lanes, pool sums in registers.
+// No data crosses waves after the block input has been staged: ONE barrier per kernel.
+// Pixel tiles of the expand are image ROWS (14 pixels + 2 repeats): a lane's LDS addresses are base + row * immediate.
 // Output: D[B][196][CE], pool[B][CE] -- what mid14_kernel writes (sums in another, equally fixed, order).
 // ---------------------------------------------------------------------------------------------
 template <int CKS, int KSD, int CE>
 __global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
 {
-    constexpr int HW = 196, NG = CE / 16, R = KSD / 2, NT = (KSD * KSD + 1) / 2;
-    constexpr int XSTR = 64 * CKS + 32;          // bytes per staged block-input row (k zero padded to 32 CKS; +32: conflict-free ds_read_b128)
-    constexpr int ESLOTS = 18 * 18 + 2;          // zero-bordered 18 x 18 grid + two scratch slots for lanes past pixel 195
-    constexpr int EREG = ESLOTS * 32;            // bytes of a wave's private region: [slot][16 channels] fp16
+    constexpr int HW = 196, NG = CE / 16, R = KSD / 2;
+    constexpr int XSTR = 64 * CKS + 16;          // bytes per staged block-input row (k zero padded to 32 CKS)
+    constexpr int ERS = 40;                      // bytes per planar row: columns x = 0 .. 15 (quads at 0, 4, 8, 12; 14, 15 stay zero) + 8 spare
+    constexpr int ECS = 736;                     // bytes per channel: 18 rows (y = -2 .. 15) + 16: the 16 x 4 lanes of a ds_read_b64 hit 64 banks
+    constexpr int EREG = 16 * ECS;               // a wave's planar region
+    constexpr int TREG = 56 * 32;                // a wave's transpose tile: [4 rows x 14 pixels][16 channels] fp16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XS = smem;                                   // [196][XSTR]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* EW = smem + HW * XSTR + wave * EREG;         // this wave's region
-    const int p = lane & 15, q = lane >> 4;
+    unsigned char* EW = smem + HW * XSTR + wave * (EREG + TREG);   // this wave's planar region
+    unsigned char* TW = EW + EREG;                                 // ... and its transpose tile
+    const int n16 = lane & 15, q = lane >> 4;    // expand role: channel n16 of the group, pixels 4q .. 4q+3 of an image row
+    // depthwise role: MFMA block lane >> 2 = channel c of the group, output row y0 + n (B / D operand), tap row i = n (A operand).
+    // Blocks map to channels so that channels 2k and 2k+1 sit in 16-lane rows r and r+1 at the same position: one
+    // v_permlane16_swap pairs their values for the transposing store (two channels of a pixel = one dword).
+    const int blk = lane >> 2, n = lane & 3;
+    const int c = 2 * (blk & 3) + ((blk >> 2) & 1) + 8 * (blk >> 3);
     const int b = blockIdx.x;
     const int Cin = a.Cin;
-    const long long ck0 = a.dbg_clk ? (long long)__builtin_readcyclecounter() : 0;
     const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
     const GLOBAL_AS float* bexp = sgpr_ptr<float>(a.bexp);
-    const GLOBAL_AS _Float16* dwd = sgpr_ptr<_Float16>(a.dwdiag);
+    const GLOBAL_AS _Float16* dwt = sgpr_ptr<_Float16>(a.dwdiag);
     const GLOBAL_AS float* bdw = sgpr_ptr<float>(a.bdw);
-    // ---- stage the block input (k zero padded) and zero this wave's region (borders stay zero for the whole kernel) ----
+    const bool clk = a.dbg_clk != nullptr;
+    long long ck[5] = {clk ? (long long)__builtin_readcyclecounter() : 0, 0, 0, 0, 0};
+    // ---- stage the block input (k zero padded) and zero this wave's planar region (borders stay zero for the whole kernel) ----
     {
         const _Float16* xg = a.X + (size_t)b * HW * Cin;
         constexpr int CPR = 4 * CKS;             // 16-byte chunks per staged row
         for (int e = tid; e < HW * CPR; e += 512) {
-            const int row = e / CPR, c = e - row * CPR;
+            const int row = e / CPR, cc = e - row * CPR;
             uint4 v = {0u, 0u, 0u, 0u};
-            if (8 * c < Cin) v = *reinterpret_cast<const uint4*>(xg + (size_t)row * Cin + 8 * c);
-            *reinterpret_cast<uint4*>(XS + row * XSTR + 16 * c) = v;
+            if (8 * cc < Cin) v = *reinterpret_cast<const uint4*>(xg + (size_t)row * Cin + 8 * cc);
+            *reinterpret_cast<uint4*>(XS + row * XSTR + 16 * cc) = v;
         }
         for (int e = lane; e < EREG / 16; e += 64) *reinterpret_cast<uint4*>(EW + 16 * e) = uint4{0u, 0u, 0u, 0u};
     }
     __syncthreads();
-    long long ck[5] = {0, 0, 0, 0, 0};
-    const bool clk = a.dbg_clk != nullptr;
     if (clk) ck[1] = (long long)__builtin_readcyclecounter();
-    // lane constants: B-operand addresses of the depthwise MFMAs for output row y are rowb + y * 18 * 32 + immediate
-    const int rowbV = p * 32 + 16 * (q & 1) + (q >> 1) * (18 * 32);   // vertical tap pairs: the second tap is one grid row down
-    const int rowbH = p * 32 + 16 * (q & 1) + (q >> 1) * 32;          // horizontal pairs: the second tap is one slot to the right
-    // operands of a channel group: expand weights (A, CKS fragments) + bias, block-diagonal depthwise fragments + bias.  The next
-    // group's are requested while the current group computes (17 KB per wave and group: an exposed L2 round trip otherwise).
-    h8 we[CKS], wd[NT], wen[CKS], wdn[NT];
-    f4 be, bd, ben, bdn;
-    auto request_group = [&](int g, h8 (&w1)[CKS], h8 (&w2)[NT], f4& b1, f4& b2) {
+    // lane constants
+    const unsigned char* xrow = XS + (n16 < 14 ? n16 : 13) * XSTR + 16 * q;              // A operand of the expand: pixel (y, min(m, 13)), + y * 14 * XSTR
+    unsigned char* est = EW + n16 * ECS + 2 * ERS + 8 * q;                                // expand store: pixels x = 4q .. 4q+3 of row y (one 8-byte store), + y * ERS
+    const uint32_t m3 = q == 3 ? 0u : 0xffffffffu;                                        // columns 14, 15 do not exist: they are written as zeros (right border)
+    const unsigned char* dld = EW + c * ECS + n * ERS + (2 - R) * ERS;                    // B operand rows y0 + n + ky - R (+2 border), + (4 yt + ky) * ERS
+    const unsigned char* dld3 = EW + c * ECS + (n < 2 ? n : 1) * ERS + (2 - R) * ERS;     // last strip (rows 12, 13): lanes n >= 2 repeat row 13
+    // transpose tile store: after the lane swap a lane of an even 16-lane row holds channels (c, c+1) of pixels x = 0 .. 6 of its
+    // row, a lane of an odd row channels (c-1, c) of pixels x = 7 .. 13: one dword per pixel at [pixel (n, x)][channel pair]
+    unsigned char* tst = TW + (n * 14 + (((blk >> 2) & 1) ? 7 : 0)) * 32 + (c >> 1) * 4;
+    // operands of a channel group: expand weights (B operand, CKS fragments) + bias, Toeplitz depthwise fragments + bias.  The next
+    // group's are requested while the current group computes (an exposed L2 round trip otherwise).
+    h8 we[CKS], wen[CKS];
+    u2v ta[KSD][2], tan[KSD][2];
+    float be, bd, ben, bdn;
+    auto request_group = [&](int g, h8 (&w1)[CKS], u2v (&w2)[KSD][2], float& b1, float& b2) {
 #pragma unroll
         for (int ks = 0; ks < CKS; ++ks) w1[ks] = gload<h8>(wexp, (unsigned)(((g * CKS + ks) * 64 + lane) * 16));
-        b1 = gload<f4>(bexp, (unsigned)(16 * g + 4 * q) * 4u);
+        b1 = gload<float>(bexp, (unsigned)(16 * g + n16) * 4u);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) w2[t] = gload<h8>(dwd, (unsigned)(((g * NT + t) * 64 + lane) * 16));
-        b2 = gload<f4>(bdw, (unsigned)(16 * g + 4 * q) * 4u);
+        for (int ky = 0; ky < KSD; ++ky)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) w2[ky][h] = gload<u2v>(dwt, (unsigned)((((g * KSD + ky) * 2 + h) * 64 + lane) * 8));
+        b2 = gload<float>(bdw, (unsigned)(16 * g + c) * 4u);
     };
     {
         const int g0 = blockIdx.y * 8 + wave;
-        request_group(g0 < NG ? g0 : 0, wen, wdn, ben, bdn);
+        request_group(g0 < NG ? g0 : 0, wen, tan, ben, bdn);
     }
 #pragma unroll 1
     for (int g = blockIdx.y * 8 + wave; g < NG; g += 8 * gridDim.y) {
 #pragma unroll
         for (int ks = 0; ks < CKS; ++ks) we[ks] = wen[ks];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wd[t] = wdn[t];
+        for (int ky = 0; ky < KSD; ++ky) { ta[ky][0] = tan[ky][0]; ta[ky][1] = tan[ky][1]; }
         be = ben;
         bd = bdn;
         {
             const int gn = g + 8 * (int)gridDim.y;
-            request_group(gn < NG ? gn : g, wen, wdn, ben, bdn);   // (the last group re-requests itself: unused)
+            request_group(gn < NG ? gn : g, wen, tan, ben, bdn);   // (the last group re-requests itself: unused)
         }
         PIN_VMEM();
-        // ---------------- expand: E[slot(pixel)][4q .. 4q+3] = silu(W_g . X[pixel] + b) for all 196 pixels ----------------
-        // Software pipeline inside the wave (it has ONE partner on its SIMD: nothing else hides its latencies): the B fragments
-        // of the next step are requested before the current step's MFMAs, and the MFMAs of step i are interleaved with the SiLU
-        // epilogue of step i - 1 (sched_group_barrier: one MFMA, then a few vector instructions).  Two pixel tiles per step.
-        auto x_frags = [&](int pt, h8 (&xb)[2][CKS]) {
+        // ---------------- expand: E[n16][y][x] = silu(X[y][x] . W_g[n16] + b) for the 14 image rows ----------------
+        // Software pipeline inside the wave (it has ONE partner on its SIMD): the A fragments of the next two rows are requested
+        // before the current rows' MFMAs, and the MFMAs of step i are interleaved with the SiLU epilogue of step i - 1.
+        auto x_frags = [&](int y, h8 (&xb)[2][CKS]) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int pix = 16 * (pt + u) + p;
-                const unsigned char* xr = XS + (pix < HW ? pix : HW - 1) * XSTR + 16 * q;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int ks = 0; ks < CKS; ++ks) xb[u][ks] = *reinterpret_cast<const h8*>(xr + 64 * ks);
-            }
+                for (int ks = 0; ks < CKS; ++ks) xb[u][ks] = *reinterpret_cast<const h8*>(xrow + (y + u) * 14 * XSTR + 64 * ks);
         };
-        auto x_epilogue = [&](int pt, const f4 (&acc)[2]) {   // SiLU + store of tiles pt, pt + 1 (pt = 12: the 14th tile does not exist)
+        auto x_epilogue = [&](int y, const f4 (&acc)[2]) {   // SiLU + store of image rows y, y + 1
             float t[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
             silu_scaled_staged(t);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int pix = 16 * (pt + u) + p;
-                const int y = (pix * 4682) >> 16, x = pix - 14 * y;                   // pix / 14, pix % 14 (exact below 224)
-                const int slot = pix < HW ? (y + 2) * 18 + x + 2 : 324 + (p & 1);     // lanes past the last pixel: scratch slots
-                const h4 o = {(_Float16)t[4 * u], (_Float16)t[4 * u + 1], (_Float16)t[4 * u + 2], (_Float16)t[4 * u + 3]};
-                *reinterpret_cast<h4*>(EW + slot * 32 + 8 * q) = o;
+                const u2v o = {cvt_pk_f16(t[4 * u], t[4 * u + 1]), cvt_pk_f16(t[4 * u + 2], t[4 * u + 3]) & m3};
+                *reinterpret_cast<u2v*>(est + (y + u) * ERS) = o;
             }
         };
         {
-            h8 xa[2][CKS], xn[2][CKS];
-            f4 accp[2] = {be, be};
-            x_frags(0, xa);
+            // (requests pinned with sched_barrier: left alone, the scheduler sinks every ds_read next to its MFMA and waits for it
+            // there -- one exposed LDS round trip per MFMA, 6.5-11 k cycles per group instead of ~2 k)
+            const f4 bev = {be, be, be, be};
+            h8 xf[2][2][CKS];       // two register sets: rows of the current step, rows of the next
+            f4 accp[2] = {bev, bev};
+            x_frags(0, xf[0]);
 #pragma unroll
-            for (int st = 0; st < 7; ++st) {          // tiles 2 st, 2 st + 1 (the 14th is a repeat of the 13th, discarded by the scratch slots)
-                if (st + 1 < 7) x_frags(2 * (st + 1) < 12 ? 2 * (st + 1) : 12, xn);   // (step 6 = tiles 12, 13: both clamp to the last pixels)
-                f4 acc[2] = {be, be};
+            for (int st = 0; st < 7; ++st) {          // image rows 2 st, 2 st + 1
+                if (st + 1 < 7) x_frags(2 * (st + 1), xf[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                f4 acc[2];
 #pragma unroll
                 for (int ks = 0; ks < CKS; ++ks)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(we[ks], xa[u][ks], acc[u], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u)   // un-swapped: rows = pixels, columns = channels; the first k-step takes the bias as its addend
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[st & 1][u][ks], we[ks], ks == 0 ? bev : acc[u], 0, 0, 0);
                 if (st > 0) x_epilogue(2 * (st - 1), accp);
                 if (st > 0) {
 #pragma unroll
                     for (int i = 0; i < 2 * CKS; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) accp[u] = acc[u];
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < CKS; ++ks) xa[u][ks] = xn[u][ks];
             }
             x_epilogue(12, accp);
         }
         if (clk && ck[2] == 0) ck[2] = (long long)__builtin_readcyclecounter();
-        // ---------------- depthwise on the matrix pipe, SiLU, store, pool sums: one output row per step, pipelined the same way
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-        _Float16* dg = a.D + (size_t)b * HW * CE + 16 * g + 4 * q;
-        auto d_frags = [&](int y, h8 (&bf)[NT]) {
-            // output row y, columns p = 0 .. 15 (14, 15 are discarded): tap (ky, kx) reads slot (y + ky + 2 - R) * 18 + p + kx + 2 - R
-            const unsigned char* bv = EW + rowbV + ((y + 2 - R) * 18 + 2 - R) * 32;
-            const unsigned char* bh = EW + rowbH + ((y + 2 - R) * 18 + 2 - R) * 32;
-            int t = 0;
+        // ---------------- depthwise on the matrix pipe (4x4x4 blocks = channels), SiLU, transpose, store, pool sums ----------------
+        // One strip of four output rows per step: KSD x 4 quads of B (ds_read_b64), KSD x 7 MFMAs into four 4x4 accumulators; the
+        // previous strip's epilogue (SiLU, pack, transpose tile, 16-byte stores) is issued beside the current strip's MFMAs.
+        float psum = 0.f;
+        unsigned char* dgb = reinterpret_cast<unsigned char*>(a.D + (size_t)b * HW * CE + 16 * g);
+        auto d_quads = [&](auto yt_tag, h4 (&bq)[KSD][4]) {   // the KSD x 4 input quads of a strip: rows y0 + n + ky - R, columns 0, 4, 8, 12
+            constexpr int YT = decltype(yt_tag)::value;
+            const unsigned char* rb = YT == 3 ? dld3 : dld;
 #pragma unroll
-            for (int ky = 0; ky + 1 < KSD; ky += 2)
+            for (int ky = 0; ky < KSD; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < KSD; ++kx, ++t) bf[t] = *reinterpret_cast<const h8*>(bv + (ky * 18 + kx) * 32);
-#pragma unroll
-            for (int kx = 0; kx < KSD; kx += 2, ++t) bf[t] = *reinterpret_cast<const h8*>(bh + ((KSD - 1) * 18 + kx) * 32);
+                for (int x4 = 0; x4 < 4; ++x4) bq[ky][x4] = *reinterpret_cast<const h4*>(rb + (4 * YT + ky) * ERS + 8 * x4);
         };
-        auto d_epilogue = [&](int y, const f4& acc) {
-            float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-            silu_scaled_staged(v);
-            const h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-            const bool ok = p < 14;
+        auto d_strip = [&](const h4 (&bq)[KSD][4], f4 (&acc)[4]) {
+            const f4 bdv = {bd, bd, bd, bd};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ps[j] += ok ? v[j] : 0.f;
-            if (ok) *reinterpret_cast<h4*>(dg + (size_t)(y * 14 + p) * CE) = o;
-        };
-        // a row's 13 (5) MFMAs run as TWO accumulation chains (even / odd tap pairs, added at the end): a single chain is paced
-        // by the dependent-accumulator latency, not by the pipe
-        auto d_row = [&](const h8 (&bf)[NT]) -> f4 {
-            f4 a0 = bd, a1 = {0.f, 0.f, 0.f, 0.f};
+            for (int ky = 0; ky < KSD; ++ky) {
+                const h4 a0 = __builtin_bit_cast(h4, ta[ky][0]), a1 = __builtin_bit_cast(h4, ta[ky][1]);
+                // output tile xt = columns 4 xt - 2 .. 4 xt + 1: quad xt with the h = 1 slice, quad xt - 1 with the h = 0 slice (tile 0's
+                // left quad is the zero border: no MFMA).  Four independent accumulators back to back, then the second round.
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t & 1) a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[t], bf[t], a1, 0, 0, 0);
-                else a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wd[t], bf[t], a0, 0, 0, 0);
+                for (int xt = 0; xt < 4; ++xt) acc[xt] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bq[ky][xt], ky == 0 ? bdv : acc[xt], 0, 0, 0);
+#pragma unroll
+                for (int xt = 1; xt < 4; ++xt) acc[xt] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bq[ky][xt - 1], acc[xt], 0, 0, 0);
             }
-            return f4{a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
+        };
+        auto d_epilogue = [&](auto yt_tag, const f4 (&acc)[4]) {
+            constexpr int YT = decltype(yt_tag)::value;
+            float v[14];
+#pragma unroll
+            for (int x = 0; x < 14; ++x) v[x] = acc[(x + 2) >> 2][(x + 2) & 3];
+            silu_scaled_staged(v);
+            float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11])) + (v[12] + v[13]);
+            if (YT == 3) s = n < 2 ? s : 0.f;   // rows 14, 15 do not exist
+            psum += s;
+#ifdef MID14M_NOSWAP
+#pragma unroll
+            for (int x = 0; x < 14; x += 2) {
+                const uint32_t hv = cvt_pk_f16(v[x], v[x + 1]);
+                *reinterpret_cast<uint16_t*>(TW + (n * 14 + x) * 32 + c * 2) = (uint16_t)hv;
+                *reinterpret_cast<uint16_t*>(TW + (n * 14 + x + 1) * 32 + c * 2) = (uint16_t)(hv >> 16);
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                // even 16-lane rows end up with (own v[j], partner's v[j]), odd rows with (partner's v[7 + j], own v[7 + j])
+                // (inline asm: hipcc 7.2 reads BOTH results of __builtin_amdgcn_permlane16_swap from the first register -- seen in the
+                // ISA as v_cvt_pk_f16_f32 v26, v27, v27; the s_nop pads are the wait states the compiler cannot see around asm)
+                float lo = v[j], hi = v[7 + j];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                *reinterpret_cast<uint32_t*>(tst + j * 32) = cvt_pk_f16(lo, hi);
+            }
+#endif
+            // the tile [56 pixels][32 B] leaves as 112 sixteen-byte vectors: lane L takes vectors L and L + 64 (the last strip has 56)
+            constexpr int NV = YT == 3 ? 56 : 112;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int vi = lane + 64 * r;
+                if (64 * r >= NV) break;
+                const uint4 o = *reinterpret_cast<const uint4*>(TW + (vi < NV ? vi : 0) * 16);
+                if (vi < NV) *reinterpret_cast<uint4*>(dgb + (size_t)(56 * YT + (vi >> 1)) * (CE * 2) + 16 * (vi & 1)) = o;
+            }
         };
         {
-            h8 ba[NT], bn[NT];
-            d_frags(0, ba);
-            d_frags(1, bn);
-            f4 accp = d_row(ba);                       // row 0 (peeled: nothing to overlap with yet)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) ba[t] = bn[t];
-#pragma unroll 1
-            for (int y = 1; y < 14; ++y) {
-                d_frags(y + 1 < 14 ? y + 1 : 13, bn);
-                const f4 acc = d_row(ba);
-                d_epilogue(y - 1, accp);               // the previous row's SiLU / store beside this row's MFMAs
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-                accp = acc;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) ba[t] = bn[t];
-            }
-            d_epilogue(13, accp);
+            // strip yt's quads are requested one strip ahead (pinned), its MFMAs run beside the previous strip's epilogue
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            h4 bqa[KSD][4], bqb[KSD][4];
+            f4 acc0[4], acc1[4];
+            d_quads(I0{}, bqa);
+            d_quads(I1{}, bqb);
+            __builtin_amdgcn_sched_barrier(0);
+            d_strip(bqa, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            d_quads(I2{}, bqa);
+            __builtin_amdgcn_sched_barrier(0);
+            d_strip(bqb, acc1);
+            d_epilogue(I0{}, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            d_quads(I3{}, bqb);
+            __builtin_amdgcn_sched_barrier(0);
+            d_strip(bqa, acc0);
+            d_epilogue(I1{}, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            d_strip(bqb, acc1);
+            d_epilogue(I2{}, acc0);
+            __builtin_amdgcn_sched_barrier(0);
+            d_epilogue(I3{}, acc1);
         }
-        // pool sums of the group's 16 channels: this lane holds 4 channels of pixel column p -> sum over the 16 columns
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s = ps[j];
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 8);
-            ps[j] = s;
-        }
-        if (p == 0) *reinterpret_cast<f4*>(a.pool + (size_t)b * CE + 16 * g + 4 * q) = f4{ps[0], ps[1], ps[2], ps[3]};
+        // pool sum of channel c: the four lanes n = 0 .. 3 hold its four row residues
+        psum += __shfl_xor(psum, 1);
+        psum += __shfl_xor(psum, 2);
+        if (n == 0) a.pool[(size_t)b * CE + 16 * g + c] = psum;
         if (clk && ck[3] == 0) ck[3] = (long long)__builtin_readcyclecounter();
     }
     if (clk && lane == 0 && (wave == 0 || wave == 4 || wave == 7)) {   // staging | first group: expand | depthwise | all remaining groups
         ck[4] = (long long)__builtin_readcyclecounter();
         float* dst = a.dbg_clk + ((size_t)b * 8 + blockIdx.y) * 16 + (wave == 0 ? 0 : (wave == 4 ? 4 : 8));
-        dst[0] = (float)(ck[1] - ck0); dst[1] = (float)(ck[2] - ck[1]); dst[2] = (float)(ck[3] - ck[2]); dst[3] = (float)(ck[4] - ck[3]);
+        dst[0] = (float)(ck[1] - ck[0]); dst[1] = (float)(ck[2] - ck[1]); dst[2] = (float)(ck[3] - ck[2]); dst[3] = (float)(ck[4] - ck[3]);
     }
 }
 
@@ -4710,7 +4747,7 @@ static int launch_mid14_t(const Mid14Args& a, hipStream_t st)
 template <int CKS, int KSD, int CE>
 static int launch_mid14m_t(const Mid14Args& a, hipStream_t st)
 {
-    const int lds = 196 * (64 * CKS + 32) + 8 * (18 * 18 + 2) * 32;   // staged block input + eight wave-private expanded regions
+    const int lds = 196 * (64 * CKS + 16) + 8 * (16 * 736 + 56 * 32);   // staged block input + eight wave-private planar regions and transpose tiles
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mid14m_kernel<CKS, KSD, CE>),

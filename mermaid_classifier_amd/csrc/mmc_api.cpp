@@ -164,7 +164,7 @@ struct BlockW {
     _Float16* t_wproj = nullptr;
     uint32_t* t_dwp = nullptr;
     uint32_t* t_dwp4 = nullptr;  // taps + bias, [4][ce][4] dwords (16-byte requests)
-    _Float16* dw_diag = nullptr;  // mid14m_kernel: block-diagonal depthwise fragments [ce/16][NT][64][8] (depthwise on the matrix pipe)
+    _Float16* dw_diag = nullptr;  // mid14m_kernel: Toeplitz depthwise fragments [ce/16][k][2][64][4] for v_mfma_f32_4x4x4_16B_f16 (depthwise on the matrix pipe)
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
     _Float16 *t_wr2 = nullptr, *t_we2 = nullptr; // ... blocks 12-15: paired rows for tail7_kernel's 16-byte requests
     // proj_patch_kernel packing (blocks 3..10): project weights/bias padded to whole fragments, SE FCs as above with
@@ -500,7 +500,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     bb->mid14 = mid14_enabled;
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
-    // MMC_MID14M=1 (default 0): blocks 6..10 on mid14m_kernel -- depthwise conv as block-diagonal MFMAs, wave-private channel
+    // MMC_MID14M=1 (default 0): blocks 6..10 on mid14m_kernel -- depthwise conv on 4x4x4 MFMA blocks (block = channel), wave-private channel
     // groups, one barrier per kernel; measured equal to mid14_kernel so far, kept as a tested variant
     const bool mid14m_enabled = mid14_enabled && [] { const char* e = getenv("MMC_MID14M"); return e && e[0] == '1'; }();
     const char* mbt_env = getenv("MMC_MBT");
@@ -574,26 +574,25 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp4, dp4));
             }
             if (mid14m_enabled && i >= 6 && i <= 10 && H == 14 && B.d.s == 1 && B.ce % 16 == 0) {
-                // Depthwise on the matrix pipe (mid14m_kernel): Y[c][p] = sum_k A[c][k] B[k][p] with k = (tap, channel') and
-                // A[c][(t, c')] = W[t][c] (c' == c).  One MFMA fragment = a 16-channel group x two taps: lane (n = l & 15, qq = l >> 4)
-                // holds k = 8 qq .. 8 qq + 7 = tap (qq >> 1 ? second : first), channels 8 (qq & 1) .. +7 of the group -- one nonzero.
-                // Tap pairs in the kernel's order: rows (ky, ky + 1) for ky = 0, 2, ... column by column, then the last kernel row in
-                // horizontal pairs; an odd tap is paired with a zero.
-                const int K = B.d.k, NT = (K * K + 1) / 2, ngr = B.ce / 16;
-                std::vector<_Float16> dd((size_t)ngr * NT * 64 * 8, (_Float16)0.0f);
-                std::vector<int> ta, tb;   // tap indices ky * K + kx (-1: none)
-                for (int ky = 0; ky + 1 < K; ky += 2)
-                    for (int kx = 0; kx < K; ++kx) { ta.push_back(ky * K + kx); tb.push_back((ky + 1) * K + kx); }
-                for (int kx = 0; kx < K; kx += 2) { ta.push_back((K - 1) * K + kx); tb.push_back(kx + 1 < K ? (K - 1) * K + kx + 1 : -1); }
+                // Depthwise on the matrix pipe (mid14m_kernel, v_mfma_f32_4x4x4_16B_f16: 16 independent blocks = 16 channels).  A operand
+                // of block c, kernel row ky, input quad h (columns x0 - 2 + 4h .. +3 of an output tile x0 .. x0+3): the Toeplitz slice
+                // A[i][k] = w[c][ky][k - i + 4h - 2 + R] (zero outside 0 .. K-1), lane 4 blk + i holding k = 0 .. 3, block blk = channel
+                // 2 (blk & 3) + ((blk >> 2) & 1) + 8 (blk >> 3) of the group (channels 2k, 2k+1 in neighbouring 16-lane rows: the kernel
+                // pairs them with v_permlane16_swap).
+                const int K = B.d.k, R = K / 2, ngr = B.ce / 16;
+                std::vector<_Float16> dd((size_t)ngr * K * 2 * 64 * 4, (_Float16)0.0f);
                 for (int g = 0; g < ngr; ++g)
-                    for (int t = 0; t < NT; ++t)
-                        for (int ln = 0; ln < 64; ++ln) {
-                            const int n = ln & 15, qq = ln >> 4;
-                            const int tapi = (qq >> 1) ? tb[t] : ta[t];
-                            const int j = n - 8 * (qq & 1);
-                            if (tapi < 0 || j < 0 || j >= 8) continue;
-                            dd[(((size_t)g * NT + t) * 64 + ln) * 8 + j] = (_Float16)(float)(w[(size_t)(16 * g + n) * kk + tapi] * tsc);
-                        }
+                    for (int ky = 0; ky < K; ++ky)
+                        for (int h = 0; h < 2; ++h)
+                            for (int ln = 0; ln < 64; ++ln) {
+                                const int blk = ln >> 2, ii = ln & 3;
+                                const int cc = 2 * (blk & 3) + ((blk >> 2) & 1) + 8 * (blk >> 3);
+                                for (int k = 0; k < 4; ++k) {
+                                    const int t = k - ii + 4 * h - 2 + R;
+                                    if (t < 0 || t >= K) continue;
+                                    dd[((((size_t)g * K + ky) * 2 + h) * 64 + ln) * 4 + k] = (_Float16)(float)(w[(size_t)(16 * g + cc) * kk + ky * K + t] * tsc);
+                                }
+                            }
                 TRY_OR_FREE(dev_upload(bb, &B.dw_diag, dd));
             }
         }

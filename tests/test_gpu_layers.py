@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def kept_backbone(checkpoint_path, request):
     """fused: expand+depthwise in one kernel (the product schedule; the expanded tensor is never in
     HBM, so there is no ``b<i>.expand`` tensor to compare).  unfused: MMC_FUSE=0, every tensor.
-    fused-mfma-dw: MMC_MID14M=1, blocks 6..10 on mid14m_kernel (depthwise conv as block-diagonal MFMAs)."""
+    fused-mfma-dw: MMC_MID14M=1, blocks 6..10 on mid14m_kernel (depthwise conv on v_mfma_f32_4x4x4_16B_f16, block = channel)."""
     os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
     if request.param == "unfused":
         os.environ["MMC_FUSE"] = "0"
