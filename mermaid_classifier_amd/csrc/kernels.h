@@ -69,6 +69,7 @@ struct TailBlock {
     const float* bproj;     // [cout]
     int cout;               // 192 (skip connection, b12..b14) or 320 (b15, no skip; must be the last block)
     int ks;                 // depthwise kernel size: 5 or 3
+    const _Float16* dwtoe;  // [72][ks][2][64][4] Toeplitz depthwise fragments of v_mfma_f32_4x4x4_16B_f16 (TailArgs::dw4), or null
 };
 struct TailArgs {
     const _Float16* X;      // [B][49][192] block input (or [B][49][320] when in_wide); unused with pre_D
@@ -102,6 +103,8 @@ struct TailArgs {
     float inv_hw;               // 1 / (49 log2 e)
     int in_wide;                // input X is [B][49][320] (head-only launches)
     int tune[4];                // experiment knobs (env MMC_T7_TUNE0..3, read by launch_tail7); 0 = off
+    int dw4;                    // 1: blocks run expand + depthwise as one wave-private phase with the depthwise conv on 4x4x4 MFMA blocks
+                                // (every TailBlock::dwtoe set); 0: the round-2 phases
 };
 int launch_tail7(const TailArgs& a, hipStream_t st);
 

@@ -60,6 +60,15 @@ static __device__ __forceinline__ float dot2_from(uint32_t a, uint32_t b, float 
     return d;
 }
 
+// Sum over the four lanes of a quad (lanes 4k .. 4k+3) on the vector ALU: two DPP quad_perm moves + adds -- __shfl_xor goes through
+// the LDS crossbar (ds_bpermute: two dependent ~130-cycle round trips).  Every lane ends up with the total, in a fixed order.
+static __device__ __forceinline__ float quad_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 // The same on N accumulators at once, stage by stage (all exponentials, all adds, all reciprocals, all products): element by
 // element the four-instruction chain exp -> add -> rcp -> mul stalls on each transcendental's latency (the compiler pads it
 // with s_nop); staged, every instruction has N - 1 independent ones between it and its consumer.  Same values, bit for bit.
@@ -1666,10 +1675,16 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 #define T7_DS11 1552                                 // row stride of block 11's depthwise output when it is produced in LDS (24 k-steps + 16)
 #define T7_OFF_X (T7_PIX * T7_ES)
 #define T7_OFF_POOL (T7_OFF_X + T7_PIX * T7_XS)
-#define T7_OFF_GATE (T7_OFF_POOL + T7_CE * 4)
+#define T7_OFF_RS (T7_OFF_POOL + T7_CE * 4)
+#define T7_OFF_GATE (T7_OFF_RS + 48 * 4)
 #define T7_OFF_PART (T7_OFF_GATE + T7_CE * 4)
-#define T7_OFF_RS (T7_OFF_PART + 32 * 48 * 4)
-#define T7_LDS (T7_OFF_RS + 48 * 4)
+// DW4 (depthwise on 4x4x4 MFMA blocks): eight wave-private planar staging regions [16 channels][12 rows][8 columns] fp16, 200 bytes
+// per channel (192 + 8: conflict-free 8-byte stores of the expand, 2-way 8-byte reads of the depthwise).  They alias gate + part (dead
+// between a block's project and its squeeze-excite) and run on to the end of the CU's 160 KB: 163 680 of 163 840 bytes.
+#define T7_PCS 200
+#define T7_OFF_STG T7_OFF_GATE
+#define T7_LDS (T7_OFF_STG + 8 * 16 * T7_PCS)
+static_assert(T7_LDS >= T7_OFF_PART + 32 * 48 * 4 && T7_LDS <= 163840, "tail7 LDS map");
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
@@ -1696,6 +1711,10 @@ static __device__ __forceinline__ T gload(const GLOBAL_AS void* base, unsigned b
 
 // SiLU of a depthwise output row inside tail7's rounds (staged: all exponentials, packed adds, reciprocals, packed products)
 #define DW_SILU(acc) silu_scaled_staged(acc)
+// DW4 = true: blocks 12..15 run expand + depthwise as ONE phase per wave and 16-channel group, the depthwise conv on
+// v_mfma_f32_4x4x4_16B_f16 (see mid14m_kernel): no barrier between the two, no thread = channel rounds, a third of the vector
+// instructions.  DW4 = false: the round-2 phases (expand, barrier, depthwise in place on v_dot2c).
+template <bool DW4>
 __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2185,6 +2204,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
             bias = __builtin_bit_cast(float, (uint32_t)t4[3].w);
         };
+        if constexpr (!DW4) {
         load_taps(tid, rawA, biasA);
         // ---------------- expand: ED = silu(X . Wexp^T + b) ----------------
         {
@@ -2292,6 +2312,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // (k0,k1)(k2,k3)(k4,0) on the pairs from x-2, output x odd (0,k0)(k1,k2)(k3,k4) on the pairs from x-3 -- the
         // values mbconv_d_kernel keeps in LDS.  KS = 3: x even (0,k0)(k1,k2) on the pairs from x-2, x odd (k0,k1)(k2,0)
         // on the pairs from x-1.  The odd/even variants are derived from the raw row pairs by shifts.
+        }
         const bool fc1_thr = tid < 384;
         const int cr = tid / 12, j4 = tid - cr * 12;   // FC1: thread = 4 outputs j x channels cr, cr+32, ...
         // Squeeze-excite weights arrive in 16-byte requests, two rows of the old 8-byte layout per request (the host pairs them:
@@ -2303,6 +2324,184 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         const bool fc2_thr = tid < 288;
         const int t2 = fc2_thr ? tid : 0;
         float brv = 0.f;
+        if constexpr (DW4) {
+        auto dw4_phase = [&](auto ks_tag) __attribute__((always_inline)) {
+            // ---------------- expand + depthwise on the matrix pipe, one 16-channel group at a time, wave-private ----------------
+            // Wave w owns groups 9w .. 9w+8.  Pixel tiles of the expand are two image rows x 8 columns (column 7 and row 7 do not
+            // exist: their slots repeat a neighbour and are written as ZEROS -- they are the right / bottom border of the planar
+            // image), un-swapped MFMA: lane (n16, q) gets channel n16 of slots 4q .. 4q+3 = columns 4 (q & 1) .. +3 of row
+            // 2t + (q >> 1): one 8-byte store into P[channel][row + 2][column].  Depthwise: block = channel, B = the quads of rows
+            // y0 + n + ky - R at columns 0 and 4, A = Toeplitz slices of the taps (host-packed, see mid14m_kernel), output tiles at
+            // columns -2, 2, 6: four MFMAs per kernel row and 4-row strip.  SiLU, pool sums, and the outputs go to ED[pixel][channel]
+            // as dwords of two channels (v_permlane16_swap pairs channels 2k, 2k+1).
+            constexpr int KS = decltype(ks_tag)::value, R = KS / 2;
+            unsigned char* SG = smem + T7_OFF_STG + wave * (16 * T7_PCS);
+            const int n16 = lane & 15;
+            const int blk = lane >> 2, n = lane & 3;
+            const int c = 2 * (blk & 3) + ((blk >> 2) & 1) + 8 * (blk >> 3);
+            const bool oddrow = (blk >> 2) & 1;
+            const GLOBAL_AS _Float16* dwt = sgpr_ptr<_Float16>(Wt.dwtoe);
+            for (int e = lane; e < T7_PCS; e += 64) *reinterpret_cast<uint4*>(SG + 16 * e) = uint4{0u, 0u, 0u, 0u};   // (gate / part of the previous block)
+            h8 xa[4][6];
+            {
+                const int sx = n16 & 7, sy = n16 >> 3;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 2 * t + sy;
+                    const int pix = (row < 7 ? row : 6) * 7 + (sx < 7 ? sx : 6);
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) xa[t][ks] = *reinterpret_cast<const h8*>(XL + pix * T7_XS + (32 * ks + 8 * q) * 2);
+                }
+            }
+            unsigned char* est = SG + n16 * T7_PCS + (2 + (q >> 1)) * 16 + (q & 1) * 8;       // + t * 32
+            const uint32_t mhi = (q & 1) ? 0x0000ffffu : 0xffffffffu;                          // column 7 -> zero
+            const uint32_t mrow3 = q >= 2 ? 0u : 0xffffffffu;                                  // tile 3: row 7 -> zeros
+            const unsigned char* dld = SG + c * T7_PCS + (n + 2 - R) * 16;                     // + (4 YT + ky) * 16 + 8 * quad
+            unsigned char* dummy = SG + c * T7_PCS + 192;                                      // 8 spare bytes per channel: masked stores land here
+            // output stores: a lane of an even 16-lane row writes columns 0 .. 3 of its row, of an odd one columns 4 .. 6 (+ a dummy)
+            unsigned char* const dst_lane = ED + (n * 7 + (oddrow ? 4 : 0)) * T7_ES + (c >> 1) * 4;
+            h8 wg[6];
+            u2v ta[KS][2];
+            float be, bd;
+            auto request_w = [&](int G) {
+#pragma unroll
+                for (int ks = 0; ks < 6; ++ks) wg[ks] = gload<h8>(W.wexp, (unsigned)(((G * 6 + ks) * 64 + lane) * 16));
+                be = gload<float>(W.bexp, (unsigned)(16 * G + n16) * 4u);
+            };
+            auto request_t = [&](int G) {
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) ta[ky][h] = gload<u2v>(dwt, (unsigned)((((G * KS + ky) * 2 + h) * 64 + lane) * 8));
+                bd = gload<float>(W.bdw, (unsigned)(16 * G + c) * 4u);
+            };
+            long long gk[4] = {0, 0, 0, 0};   // phase clock of the group loop (MMC_TAIL_CLK=1): expand MFMAs | SiLU + store | depthwise MFMAs | epilogue
+            auto group = [&](int G, auto last_tag) __attribute__((always_inline)) {
+                constexpr bool LAST = decltype(last_tag)::value;
+                long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                if (clk_on) g0 = (long long)__builtin_readcyclecounter();
+                request_t(G);
+                PIN_VMEM();
+                // ---- expand ----
+                f4 acc[4];
+                {
+                    const f4 bev = {be, be, be, be};
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[t][ks], wg[ks], ks == 0 ? bev : acc[t], 0, 0, 0);
+                }
+                if (!LAST) request_w(G + 1);      // the weight registers are free again: next group's fragments arrive during the depthwise part
+                else {
+                    // last group: the pixel fragments are dead -- the squeeze-excite weights are requested now (see the round-2 phases)
+                    const int crl = fc1_thr ? cr : 0;
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) fw1[i] = gload<u4v>(W.wr_t, (unsigned)((i * 384 + crl * 12 + j4) * 16));
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) fw2[k] = gload<u4v>(W.we_t, (unsigned)((k * 288 + t2) * 16));
+                    brv = tid < 48 ? gload<float>(W.br, (unsigned)tid * 4u) : 0.f;
+                }
+                PIN_VMEM();
+                if (clk_on) g1 = (long long)__builtin_readcyclecounter();
+                {
+                    float t16[16];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t16[4 * t + j] = acc[t][j];
+                    silu_scaled_staged(t16);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        u2v o = {cvt_pk_f16(t16[4 * t], t16[4 * t + 1]), cvt_pk_f16(t16[4 * t + 2], t16[4 * t + 3]) & mhi};
+                        if (t == 3) { o.x &= mrow3; o.y &= mrow3; }
+                        *reinterpret_cast<u2v*>(est + t * 32) = o;
+                    }
+                }
+                if (clk_on) g2 = (long long)__builtin_readcyclecounter();
+                // ---- depthwise (the wave reads back what it wrote: LDS operations of a wave complete in order) ----
+                f4 dacc[2][3];
+                {
+                    // the quads of kernel rows 0 .. KB-1 are requested at once, the rest behind them while the first batch computes (one
+                    // kernel row ahead the 8 MFMAs of a row -- 67 cycles -- did not cover an LDS round trip: 1.2 k cycles per group for 40 MFMAs)
+                    const f4 bdv = {bd, bd, bd, bd};
+                    constexpr int KB = KS == 5 ? 3 : KS;
+                    h4 bq[KS][2][2];
+                    auto quads = [&](int k0, int k1) {
+#pragma unroll
+                        for (int ky = k0; ky < k1; ++ky)
+#pragma unroll
+                            for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+                                for (int xq = 0; xq < 2; ++xq) bq[ky][yt][xq] = *reinterpret_cast<const h4*>(dld + (4 * yt + ky) * 16 + 8 * xq);
+                    };
+                    auto rows = [&](int k0, int k1) {
+#pragma unroll
+                        for (int ky = k0; ky < k1; ++ky) {
+                            const h4 a0 = __builtin_bit_cast(h4, ta[ky][0]), a1 = __builtin_bit_cast(h4, ta[ky][1]);
+                            // output tile xt = columns 4 xt - 2 .. 4 xt + 1: quad xt with the h = 1 slice, quad xt - 1 with the h = 0 slice
+#pragma unroll
+                            for (int yt = 0; yt < 2; ++yt) {
+                                dacc[yt][0] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bq[ky][yt][0], ky == 0 ? bdv : dacc[yt][0], 0, 0, 0);
+                                dacc[yt][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bq[ky][yt][1], ky == 0 ? bdv : dacc[yt][1], 0, 0, 0);
+                                dacc[yt][2] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bq[ky][yt][1], ky == 0 ? bdv : dacc[yt][2], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int yt = 0; yt < 2; ++yt) dacc[yt][1] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bq[ky][yt][0], dacc[yt][1], 0, 0, 0);
+                        }
+                    };
+                    quads(0, KB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (KB < KS) quads(KB, KS);
+                    __builtin_amdgcn_sched_barrier(0);
+                    rows(0, KB);
+                    if (KB < KS) rows(KB, KS);
+                }
+                if (clk_on) g3 = (long long)__builtin_readcyclecounter();
+                {
+                    float v[14];   // [strip][column]: column x = 4 xt - 2 + i
+#pragma unroll
+                    for (int yt = 0; yt < 2; ++yt)
+#pragma unroll
+                        for (int x = 0; x < 7; ++x) v[7 * yt + x] = dacc[yt][(x + 2) >> 2][(x + 2) & 3];
+                    silu_scaled_staged(v);
+                    const float s0 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
+                    const float s1 = ((v[7] + v[8]) + (v[9] + v[10])) + ((v[11] + v[12]) + v[13]);
+                    const float psum = quad_sum(s0 + (n < 3 ? s1 : 0.f));   // row 7 does not exist
+                    if (n == 0) pooled[16 * G + c] = psum;
+                    unsigned char* d0 = dst_lane + 32 * G;
+#pragma unroll
+                    for (int yt = 0; yt < 2; ++yt) {
+                        const bool norow = yt == 1 && n == 3;   // row 7 does not exist: its lanes store to the spare bytes
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            // even rows end up with (own column j, partner's column j), odd rows with (partner's column 4 + j, own column 4 + j)
+                            float lo = v[7 * yt + j], hi = j < 3 ? v[7 * yt + 4 + j] : 0.f;
+                            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                            unsigned char* dp = d0 + (28 * yt + j) * T7_ES;
+                            if (norow || (j == 3 && oddrow)) dp = dummy;   // (column 7 does not exist either)
+                            *reinterpret_cast<uint32_t*>(dp) = cvt_pk_f16(lo, hi);
+                        }
+                    }
+                }
+                if (clk_on) {
+                    const long long g4 = (long long)__builtin_readcyclecounter();
+                    gk[0] += g1 - g0; gk[1] += g2 - g1; gk[2] += g3 - g2; gk[3] += g4 - g3;
+                }
+            };
+            request_w(9 * wave);
+#pragma unroll 1
+            for (int g = 0; g < 8; ++g) group(9 * wave + g, std::false_type{});
+            group(9 * wave + 8, std::true_type{});
+            if (clk_on && nb == 0 && lane == 0 && (wave == 0 || wave == 4))   // section 7: the four sums of waves 0 and 4 (SIMD-mates), first block
+                for (int i = 0; i < 4; ++i) a.dbg_clk[((size_t)b * 8 + 7) * 8 + (wave ? 4 : 0) + i] = (float)gk[i];
+        };
+            if (ks3) dw4_phase(std::integral_constant<int, 3>{});
+            else dw4_phase(std::integral_constant<int, 5>{});
+            T7_BAR();
+            T7_TICK();
+            T7_TICK();
+        } else {
         auto dw_phase = [&](auto ks_tag) __attribute__((always_inline)) {
             constexpr int KS = decltype(ks_tag)::value, R = KS / 2, NP = KS == 5 ? 3 : 2;
             auto tap_pairs = [&](const uint32_t (&raw)[15], uint32_t (&wp)[2 * KS * NP]) {
@@ -2467,6 +2666,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         else dw_phase(std::integral_constant<int, 5>{});
         T7_BAR();
         T7_TICK();
+        }
         if (a.dbg_dw) {
             _Float16* dg = a.dbg_dw + (size_t)b * T7_PIX * T7_CE;
             for (int e = tid; e < T7_PIX * 144; e += 512) {
@@ -3186,8 +3386,7 @@ __global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
             d_epilogue(I3{}, acc1);
         }
         // pool sum of channel c: the four lanes n = 0 .. 3 hold its four row residues
-        psum += __shfl_xor(psum, 1);
-        psum += __shfl_xor(psum, 2);
+        psum = quad_sum(psum);
         if (n == 0) a.pool[(size_t)b * CE + 16 * g + c] = psum;
         if (clk && ck[3] == 0) ck[3] = (long long)__builtin_readcyclecounter();
     }
@@ -4651,8 +4850,10 @@ int launch_tail7(const TailArgs& a, hipStream_t st)
     if (a.pre_X && (!a.pre_wexp || !a.pre_bexp || !a.pre_dwp || !a.pre_bdw)) return -9;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, T7_LDS);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail7_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T7_LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
@@ -4666,7 +4867,8 @@ int launch_tail7(const TailArgs& a, hipStream_t st)
         }
     TailArgs aa = a;
     for (int i = 0; i < 4; ++i) aa.tune[i] = tune[i];
-    hipLaunchKernelGGL(tail7_kernel, dim3(a.B), dim3(512), T7_LDS, st, aa);
+    if (a.dw4) hipLaunchKernelGGL(tail7_kernel<true>, dim3(a.B), dim3(512), T7_LDS, st, aa);
+    else hipLaunchKernelGGL(tail7_kernel<false>, dim3(a.B), dim3(512), T7_LDS, st, aa);
     LAUNCH_CHECK();
     return 0;
 }

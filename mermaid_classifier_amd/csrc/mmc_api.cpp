@@ -273,6 +273,7 @@ struct mmc_backbone {
     bool tail_b11 = false;           // block 11's front half (expand + depthwise stride 2) inside tail7_kernel too: no b11 launch at all
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
+    bool tail_dw4 = true;            // every tail block has its Toeplitz depthwise fragments (only with MMC_TAIL_DW4=1)
     std::map<std::string, Saved> saved;
     int last_n = 0;
     // One pass at a time per handle (lane workspaces, fork/done events and the staging buffers are shared): calls are
@@ -503,6 +504,11 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     // MMC_MID14M=1 (default 0): blocks 6..10 on mid14m_kernel -- depthwise conv on 4x4x4 MFMA blocks (block = channel), wave-private channel
     // groups, one barrier per kernel; measured equal to mid14_kernel so far, kept as a tested variant
     const bool mid14m_enabled = mid14_enabled && [] { const char* e = getenv("MMC_MID14M"); return e && e[0] == '1'; }();
+    // MMC_TAIL_DW4=1 (default 0): tail7_kernel's blocks 12..15 with the depthwise conv on 4x4x4 MFMA blocks, fused with the expand into one
+    // wave-private phase.  Parity-tested; measured 44-45 k cycles per block for expand + depthwise against 40.6 k for the round-2 phases
+    // (45 % fewer vector instructions, but the 4x4x4 MFMAs hold the issue port half their time and the phase does not
+    // overlap its matrix and vector halves at two waves per SIMD), so it stays opt-in.
+    const bool tail_dw4 = [] { const char* e = getenv("MMC_TAIL_DW4"); return e && e[0] == '1'; }();
     const char* mbt_env = getenv("MMC_MBT");
     const bool mbt_enabled = (fuse_enabled || fuse_generic_early) && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
@@ -573,7 +579,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp4, dp4));
             }
-            if (mid14m_enabled && i >= 6 && i <= 10 && H == 14 && B.d.s == 1 && B.ce % 16 == 0) {
+            if (((mid14m_enabled && i >= 6 && i <= 10 && H == 14) || (tail_dw4 && tail_enabled && i >= 12 && i <= 15 && H == 7)) && B.d.s == 1 && B.ce % 16 == 0) {
                 // Depthwise on the matrix pipe (mid14m_kernel, v_mfma_f32_4x4x4_16B_f16: 16 independent blocks = 16 channels).  A operand
                 // of block c, kernel row ky, input quad h (columns x0 - 2 + 4h .. +3 of an output tile x0 .. x0+3): the Toeplitz slice
                 // A[i][k] = w[c][ky][k - i + 4h - 2 + R] (zero outside 0 .. K-1), lane 4 blk + i holding k = 0 .. 3, block blk = channel
@@ -845,7 +851,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             for (int j = 0; j < 4; ++j) {
                 const BlockW& B = bb->blk[12 + j];
                 tab[j] = TailBlock{B.exp_frag, B.expand.b, B.t_dwp4, B.dw_b, B.t_wr2, B.se_br, B.t_we2, B.se_be, B.t_wproj, B.project.b,
-                                   B.d.cout, B.d.k};
+                                   B.d.cout, B.d.k, B.dw_diag};
+                bb->tail_dw4 = bb->tail_dw4 && B.dw_diag != nullptr;
             }
             TRY_OR_FREE(dev_upload(bb, &bb->tail_tab, tab));
             const char* tf = getenv("MMC_TAIL_FULL");
@@ -991,13 +998,13 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             // blocks 12..15 in one launch, one patch per workgroup, tensors resident in LDS (tail7_kernel)
             if (!bb->keep) {
                 TailArgs ta{};
-                ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 4; ta.blk = bb->tail_tab;
+                ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 4; ta.blk = bb->tail_tab; ta.dw4 = bb->tail_dw4;
                 STEP("b12-15.tail", "tail7", launch_tail7(ta, st));
                 _Float16* t = x; x = y; y = t;
             } else {
                 for (int j = 0; j < 4; ++j) {   // block at a time so every intermediate tensor can be read back
                     TailArgs ta{};
-                    ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 1; ta.blk = bb->tail_tab + j;
+                    ta.X = x; ta.Y = y; ta.B = n; ta.nblk = 1; ta.blk = bb->tail_tab + j; ta.dw4 = bb->tail_dw4;
                     ta.dbg_dw = ws.dwbuf; ta.dbg_gate = ws.gate; ta.dbg_clk = ws.pool_part;
                     snprintf(nm, sizeof nm, "b%d.tail", 12 + j);
                     STEP(nm, "tail7", launch_tail7(ta, st));
@@ -1033,7 +1040,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
         if (i == 11 && bb->tail_full && bb->tail_b11 && !bb->keep) {
             // the whole of block 11, blocks 12..15 and the head conv in ONE launch: from block 10's output to the feature vector
             TailArgs ta{};
-            ta.B = n; ta.blk = bb->tail_tab; ta.nblk = 4;
+            ta.B = n; ta.blk = bb->tail_tab; ta.nblk = 4; ta.dw4 = bb->tail_dw4;
             ta.pre_X = x; ta.pre_wexp = B.exp_frag; ta.pre_bexp = B.expand.b; ta.pre_dwp = B.t_dwp4; ta.pre_bdw = B.dw_b;
             ta.pre_wr_t = B.t_wr; ta.pre_br = B.pp_br; ta.pre_we_t = B.t_we; ta.pre_be = B.se_be; ta.pre_wproj = bb->pre_wproj;
             ta.pre_bproj = B.project.b; ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));
@@ -1134,7 +1141,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             // the last 14x14 depthwise output straight to the feature vector.  Per-tensor mode runs it in pieces.
             const BlockW& B11 = B;
             TailArgs ta{};
-            ta.B = n; ta.blk = bb->tail_tab;
+            ta.B = n; ta.blk = bb->tail_tab; ta.dw4 = bb->tail_dw4;
             ta.pre_D = ws.dwbuf; ta.pre_pool = ws.pool_part; ta.pre_wr_t = B11.t_wr; ta.pre_br = B11.pp_br; ta.pre_we_t = B11.t_we;
             ta.pre_be = B11.se_be; ta.pre_wproj = bb->pre_wproj; ta.pre_bproj = B11.project.b;
             ta.inv_hw = (float)(1.0 / (49.0 * LOG2E));

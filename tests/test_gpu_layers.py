@@ -15,12 +15,14 @@ pytestmark = pytest.mark.gpu
 def kept_backbone(checkpoint_path, request):
     """fused: expand+depthwise in one kernel (the product schedule; the expanded tensor is never in
     HBM, so there is no ``b<i>.expand`` tensor to compare).  unfused: MMC_FUSE=0, every tensor.
-    fused-mfma-dw: MMC_MID14M=1, blocks 6..10 on mid14m_kernel (depthwise conv on v_mfma_f32_4x4x4_16B_f16, block = channel)."""
+    fused-mfma-dw: MMC_MID14M=1 and MMC_TAIL_DW4=1, blocks 6..10 on mid14m_kernel and blocks 12..15 on tail7_kernel<true> (depthwise conv
+    on v_mfma_f32_4x4x4_16B_f16, block = channel)."""
     os.environ["MMC_KEEP_ACTIVATIONS"] = "1"
     if request.param == "unfused":
         os.environ["MMC_FUSE"] = "0"
     if request.param == "fused-mfma-dw":
         os.environ["MMC_MID14M"] = "1"
+        os.environ["MMC_TAIL_DW4"] = "1"
     try:
         from mermaid_classifier_amd.backbone import Backbone
         bb = Backbone(str(checkpoint_path), device=0, max_batch=4)
@@ -28,6 +30,7 @@ def kept_backbone(checkpoint_path, request):
         os.environ.pop("MMC_KEEP_ACTIVATIONS", None)
         os.environ.pop("MMC_FUSE", None)
         os.environ.pop("MMC_MID14M", None)
+        os.environ.pop("MMC_TAIL_DW4", None)
     bb.mode = "unfused" if request.param == "unfused" else "fused"
     yield bb
     bb.close()

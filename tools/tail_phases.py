@@ -32,6 +32,9 @@ def main():
     names = ["expand", "dw", "fc1", "fc2", "gate", "project"]
     for s in range(1, 5):
         print(f"b{11 + s} : " + "  ".join(f"{nm} {c:7.0f}" for nm, c in zip(names, med[s][:6])) + f"   total {med[s][:6].sum():8.0f}")
+    if med[7].any():
+        print("b12 group loop (DW4), sums over 9 groups: expand MFMAs | SiLU + store | depthwise MFMAs | epilogue")
+        print("  wave 0: " + " | ".join(f"{c:7.0f}" for c in med[7][:4]) + "    wave 4: " + " | ".join(f"{c:7.0f}" for c in med[7][4:]))
     if os.environ.get("MMC_MID14M") != "1":
         print(f"head: {med[5][0]:7.0f}   whole kernel {med[6][0]:8.0f} cycles (median over {n} workgroups)")
         return
