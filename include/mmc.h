@@ -65,6 +65,17 @@ int mmc_device_count(void);     /* number of visible HIP devices (0 when none) *
  */
 int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device, int max_batch,
                         mmc_backbone** out);
+/* The same with `flags`.  MMC_PRECISION_FP8 (MMC_ARCH_B4 only; BASELINE.json configs[4], not in the reference): the squeeze-excite
+ * gated project convs of the 7x7 stage (env MMC_FP8_MAXH=14: of the 14x14 stages too) run on OCP e4m3 operands
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation): weights quantised at create time with one scale per output channel,
+ * activations in the kernel with one scale per pixel.  Everything else stays fp16 storage / fp32 accumulation.  Accuracy is that of
+ * the operand format, not the fp16 gates: feature cosine >= 0.997 against the fp32 oracle on image-like patches (tests). */
+#define MMC_PRECISION_FP8 1u
+int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arch, int device, int max_batch, unsigned flags,
+                           mmc_backbone** out);
+/* fp32 -> OCP e4m3fn bytes (round to nearest even, saturating at +-448): the encoding the fp8 weights are stored in.  Host code,
+ * no device needed; exported so that tests can check it against an independent implementation. */
+int mmc_fp8_e4m3_encode(const float* in, uint8_t* out, size_t n);
 void mmc_backbone_destroy(mmc_backbone* bb);
 int mmc_feature_dim(const mmc_backbone* bb);            /* 1280 for B0, 1792 for B4 */
 int mmc_backbone_max_batch(const mmc_backbone* bb);

@@ -13,12 +13,13 @@ LIB_NAME = "libmermaid_mi355.so"
 LIB_PATH = _HERE / LIB_NAME
 
 MMC_OK, MMC_ERR_ARG, MMC_ERR_WEIGHTS, MMC_ERR_HIP, MMC_ERR_NOMEM = 0, 1, 2, 3, 4
+MMC_PRECISION_FP8 = 1   # include/mmc.h: flags of mmc_backbone_create_ex
 MMC_IN_HOST, MMC_OUT_HOST = 1, 2
 
 # every symbol include/mmc.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = [
     "mmc_last_error", "mmc_version", "mmc_device_count",
-    "mmc_backbone_create", "mmc_backbone_destroy", "mmc_feature_dim", "mmc_backbone_max_batch", "mmc_backbone_lanes",
+    "mmc_backbone_create", "mmc_backbone_create_ex", "mmc_fp8_e4m3_encode", "mmc_backbone_destroy", "mmc_feature_dim", "mmc_backbone_max_batch", "mmc_backbone_lanes",
     "mmc_backbone_workspace_bytes", "mmc_backbone_extract", "mmc_backbone_read_activation",
     "mmc_backbone_profile", "mmc_backbone_graph_stats", "mmc_crop_patches",
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
@@ -54,6 +55,10 @@ def _load() -> C.CDLL:
     lib.mmc_device_count.restype = i32
     lib.mmc_backbone_create.restype = i32
     lib.mmc_backbone_create.argtypes = [vp, sz, i32, i32, i32, C.POINTER(vp)]
+    lib.mmc_backbone_create_ex.restype = i32
+    lib.mmc_backbone_create_ex.argtypes = [vp, sz, i32, i32, i32, u32, C.POINTER(vp)]
+    lib.mmc_fp8_e4m3_encode.restype = i32
+    lib.mmc_fp8_e4m3_encode.argtypes = [vp, vp, sz]
     lib.mmc_backbone_destroy.restype = None
     lib.mmc_backbone_destroy.argtypes = [vp]
     lib.mmc_feature_dim.restype = i32

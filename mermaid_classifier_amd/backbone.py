@@ -52,7 +52,11 @@ class Backbone:
     ``arch``: None = efficientnet-b0 for a checkpoint stream (what the reference path loads) and
     detected from the stem width for a state dict; "b0" / "b4" to insist."""
 
-    def __init__(self, weights, device=0, max_batch: int = 256, arch=None):
+    def __init__(self, weights, device=0, max_batch: int = 256, arch=None, precision: str = "fp16"):
+        """precision: "fp16" (fp16 storage and MFMA operands, fp32 accumulation) or "fp8" (EfficientNet-B4 only, BASELINE configs[4]: the
+        7x7 stage's project convs on OCP e4m3 MFMA operands -- include/mmc.h MMC_PRECISION_FP8)."""
+        if precision not in ("fp16", "fp8"):
+            raise ValueError(f"precision must be 'fp16' or 'fp8', got {precision!r}")
         lib = _lib.lib()
         if isinstance(weights, dict):
             sd = {}
@@ -75,8 +79,9 @@ class Backbone:
         self.device_index = _device_index(device)
         self._h = C.c_void_p()
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        _lib.check(lib.mmc_backbone_create(C.cast(buf, C.c_void_p), len(blob), A.arch_id, self.device_index,
-                                           int(max_batch), C.byref(self._h)))
+        self.precision = precision
+        _lib.check(lib.mmc_backbone_create_ex(C.cast(buf, C.c_void_p), len(blob), A.arch_id, self.device_index,
+                                              int(max_batch), _lib.MMC_PRECISION_FP8 if precision == "fp8" else 0, C.byref(self._h)))
         self.max_batch = int(max_batch)
         self.feature_dim = lib.mmc_feature_dim(self._h)
         self.lanes = lib.mmc_backbone_lanes(self._h)

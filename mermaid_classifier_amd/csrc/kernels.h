@@ -26,6 +26,23 @@ struct GemmArgs {
     float inv_hw;
 };
 
+// Project conv on fp8 (OCP e4m3) MFMA operands (pw_gemm_fp8_kernel; BASELINE configs[4]): weights quantised on the host with one
+// scale per output channel, activations (x * squeeze-excite gate) quantised in the kernel with one scale per pixel row.
+struct Fp8GemmArgs {
+    const _Float16* X;   // [M][K] depthwise output (NHWC rows), K a multiple of 8
+    int M, K;
+    const uint8_t* W8;   // [NFp][KS128][64 lanes][32] e4m3: fragment f = channels 16 f .. +15, lane (i, q) holds k = 128 ks + 32 q .. +31 of channel 16 f + i
+    int KS128, NFp;      // k-steps of 128 (K zero padded), fragments (padded to whole workgroups of 7)
+    const float* sw;     // [16 NFp] weight scales (0 for padding channels)
+    const float* bias;   // [16 NFp]
+    _Float16* Y;         // [M][N]
+    int N;
+    const float* gate;   // [patch][K]
+    int HW;              // rows per patch
+    const _Float16* res; // [M][N] or null
+};
+int launch_pw_gemm_fp8(const Fp8GemmArgs& a, hipStream_t st);
+
 struct DwArgs {
     const _Float16* in;
     const float* wt;     // [ks*ks][C]

@@ -412,6 +412,107 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// pw_gemm_fp8_kernel: SE-scale + project conv (+ skip) on fp8 MFMA operands -- BASELINE.json configs[4] ("EfficientNet-B4, fp8
+// weights/activations on CDNA4 fp8 MFMA"; not in the reference).  v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands and unit
+// block scales: K = 128 per instruction at twice the fp16 rate (tools/ubench/mfma_f8.hip: layout and cycles).
+//   weights      e4m3, one fp32 scale per output channel (amax / 448), quantised and packed in fragment order on the host
+//   activations  the fp16 depthwise output times its fp32 squeeze-excite gate, one fp32 scale per pixel row (amax / 447 of the
+//                gated row), quantised here: pass 1 reads the row for its maximum, pass 2 reads it again (L2 / Infinity Cache),
+//                scales, converts (v_cvt_pk_fp8_f32) and feeds the MFMAs
+//   epilogue     y = acc * row scale * channel scale + bias (+ skip) -> fp16
+// Operands are swapped as in pw_gemm_kernel (A = weights, B = pixels): a lane ends up with 4 consecutive channels of one pixel.
+// One workgroup = 4 waves x 16 pixel rows x NT output fragments.
+// ---------------------------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+template <int NT, bool RES>
+__global__ __launch_bounds__(256) void pw_gemm_fp8_kernel(Fp8GemmArgs a)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + m;
+    const bool rok = row < a.M;
+    const int rowc = rok ? row : a.M - 1;
+    const _Float16* xr = a.X + (size_t)rowc * a.K;
+    const float* gr = a.gate + (size_t)(rowc / a.HW) * a.K;
+    const int f0 = blockIdx.y * NT;
+    // one k-step of this lane: 32 channels from 128 ks + 32 q, as x * gate in fp32 (zeros past K)
+    auto gated = [&](int ks, float (&v)[32]) {
+        const int k0 = 128 * ks + 32 * q;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            const int k = k0 + 8 * c8;
+            h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+            f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+            if (k < a.K) {
+                x = *reinterpret_cast<const h8*>(xr + k);
+                g0 = *reinterpret_cast<const f4*>(gr + k);
+                g1 = *reinterpret_cast<const f4*>(gr + k + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[8 * c8 + j] = (float)x[j] * g0[j]; v[8 * c8 + 4 + j] = (float)x[4 + j] * g1[j]; }
+        }
+    };
+    // ---- pass 1: the row's largest magnitude ----
+    float mx = 0.f;
+    for (int ks = 0; ks < a.KS128; ++ks) {
+        float v[32];
+        gated(ks, v);
+#pragma unroll
+        for (int e = 0; e < 32; e += 2) mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fabsf(v[e]), __builtin_fabsf(v[e + 1])));
+    }
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16));
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32));
+    // 447 (not 448): the scaled maximum stays below e4m3's largest finite value after fp32 rounding
+    const float inv = mx > 0.f ? 447.0f / mx : 0.f;
+    const float sx = mx > 0.f ? mx * (1.0f / 447.0f) : 0.f;
+    // ---- pass 2: quantise and multiply ----
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    const uint8_t* wl = a.W8 + (size_t)lane * 32;
+    for (int ks = 0; ks < a.KS128; ++ks) {
+        float v[32];
+        gated(ks, v);
+        v8i bq;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d] * inv, v[4 * d + 1] * inv, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * d + 2] * inv, v[4 * d + 3] * inv, w, true);
+            bq[d] = w;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint8_t* wp = wl + ((size_t)(f0 + t) * a.KS128 + ks) * 2048;
+            union { uint4 u[2]; v8i v; } aw;
+            aw.u[0] = *reinterpret_cast<const uint4*>(wp);
+            aw.u[1] = *reinterpret_cast<const uint4*>(wp + 16);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aw.v, bq, acc[t], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+    }
+    // ---- epilogue: lane (m, q) holds channels 16 (f0 + t) + 4 q + j of pixel row m ----
+    if (!rok) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = 16 * (f0 + t) + 4 * q;
+        if (c >= a.N) continue;   // N is a multiple of 4
+        const f4 sw = *reinterpret_cast<const f4*>(a.sw + c), bv = *reinterpret_cast<const f4*>(a.bias + c);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[t][j] * sx * sw[j] + bv[j];
+        if (RES) {
+            const h4 r = *reinterpret_cast<const h4*>(a.res + (size_t)row * a.N + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+        }
+        h4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+        *reinterpret_cast<h4*>(a.Y + (size_t)row * a.N + c) = o;
+    }
+}
+
 static __device__ __forceinline__ uint4 gate_h8(uint4 x, f4 g0, f4 g1)
 {
     // eight fp16 activations times their fp32 gates -> eight fp16 (each product in fp32, rounded once):
@@ -4580,6 +4681,16 @@ int launch_pw_gemm(const GemmArgs& a, hipStream_t st)
         default: return -3;
     }
 #undef CASE_NT
+}
+
+int launch_pw_gemm_fp8(const Fp8GemmArgs& a, hipStream_t st)
+{
+    if (a.M < 1 || (a.K & 7) || (a.N & 3) || a.KS128 * 128 < a.K || a.NFp % 7 || 16 * a.NFp < a.N || !a.gate || a.HW < 1) return -17;
+    dim3 grid((a.M + 63) / 64, a.NFp / 7);
+    if (a.res) hipLaunchKernelGGL((pw_gemm_fp8_kernel<7, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pw_gemm_fp8_kernel<7, false>), grid, dim3(256), 0, st, a);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 int thin_proj_has(int ksteps) { return ksteps >= 1 && ksteps <= 6; }   // the k-step counts launch_thin_proj instantiates

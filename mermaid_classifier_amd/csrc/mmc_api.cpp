@@ -121,6 +121,44 @@ struct PwLayer {
     float* b = nullptr;     // device [n_chunks*16*nt]
 };
 
+// A project conv with e4m3 weights for pw_gemm_fp8_kernel (MMC_PRECISION_FP8)
+struct Fp8Layer {
+    int N = 0, K = 0, KS128 = 0, NFp = 0;
+    uint8_t* w8 = nullptr;  // device [NFp][KS128][64][32]
+    float* sw = nullptr;    // device [16 NFp] per-output-channel scales
+    float* b = nullptr;     // device [16 NFp]
+};
+
+// fp32 -> OCP e4m3fn (4 exponent bits, bias 7, 3 mantissa bits, no infinities, largest finite 448), round to nearest even,
+// saturating.  The device side uses v_cvt_pk_fp8_f32; the host needs the same encoding for the weights.
+static uint8_t e4m3_encode(float x)
+{
+    if (x != x) return 0x7F;
+    const uint8_t sign = std::signbit(x) ? 0x80 : 0x00;
+    float a = std::fabs(x);
+    if (a >= 448.0f) return sign | 0x7E;
+    if (a < 0.0009765625f) return sign;                        // below half of the smallest subnormal (2^-9): zero (a tie goes to even = 0)
+    int e;
+    (void)std::frexp(a, &e);                                   // a = f * 2^e, f in [0.5, 1)
+    int ex = e - 1;                                            // a in [2^ex, 2^(ex+1))
+    if (ex < -6) ex = -6;                                      // subnormals share the exponent of the smallest normal
+    const float quantum = std::ldexp(1.0f, ex - 3);
+    float qf = std::nearbyint(a / quantum);                    // round to nearest even (default rounding mode)
+    int qi = (int)qf;
+    if (qi >= 16) { qi = 8; ++ex; }
+    if (ex > 8) return sign | 0x7E;
+    if (ex == 8 && qi > 14) return sign | 0x7E;                // 448 = 1.75 * 2^8 is the largest finite value
+    if (qi < 8) return sign | (uint8_t)qi;                     // subnormal (only with ex == -6)
+    return sign | (uint8_t)(((ex + 7) << 3) | (qi - 8));
+}
+
+extern "C" int mmc_fp8_e4m3_encode(const float* in, uint8_t* out, size_t n)
+{
+    if (!in || !out) return fail(MMC_ERR_ARG, "NULL argument");
+    for (size_t i = 0; i < n; ++i) out[i] = e4m3_encode(in[i]);
+    return MMC_OK;
+}
+
 // Channel fragments (16 wide) per workgroup.  Big-M layers (early blocks) take the widest chunk that
 // divides N (X is read once per chunk).  Small-M layers (14x14 and 7x7 blocks, head) take narrow
 // chunks: more workgroups and registers left for a 4-step-deep fragment prefetch; X re-reads hit L2.
@@ -145,6 +183,7 @@ struct BlockW {
     int H = 0, Ho = 0, ce = 0, cs = 0, cs4 = 0, pad = 0;
     bool has_expand = false, skip = false;
     PwLayer expand, project;
+    Fp8Layer p8;             // the project conv on fp8 operands (MMC_PRECISION_FP8, blocks from fp8_from on)
     float *dw_w = nullptr, *dw_b = nullptr;                    // [k*k][ce], [ce]
     float *se_br = nullptr, *se_be = nullptr;
     float *se_wrp = nullptr, *se_wep = nullptr;   // fragment-ordered fp32 squeeze-excite weights
@@ -272,6 +311,8 @@ struct mmc_backbone {
     bool tail_full = false;
     bool tail_b11 = false;           // block 11's front half (expand + depthwise stride 2) inside tail7_kernel too: no b11 launch at all
     _Float16 *pre_wproj = nullptr, *head_wfrag = nullptr;
+    bool fp8 = false;                // MMC_PRECISION_FP8: project convs of blocks fp8_from .. on e4m3 MFMA operands
+    int fp8_from = 0;
     TailBlock* tail_tab = nullptr;   // device table for tail7_kernel (blocks 12..14), null = separate launches
     bool tail_dw4 = true;            // every tail block has its Toeplitz depthwise fragments (only with MMC_TAIL_DW4=1)
     std::map<std::string, Saved> saved;
@@ -405,7 +446,16 @@ extern "C" void mmc_backbone_destroy(mmc_backbone* bb)
 extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, int device, int max_batch,
                                    mmc_backbone** out)
 {
+    return mmc_backbone_create_ex(packed, nbytes, arch, device, max_batch, 0u, out);
+}
+
+extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arch, int device, int max_batch, unsigned flags,
+                                      mmc_backbone** out)
+{
     if (!out) return fail(MMC_ERR_ARG, "out is NULL");
+    if (flags & ~(unsigned)MMC_PRECISION_FP8) return fail(MMC_ERR_ARG, "unknown flags 0x%x", flags);
+    if ((flags & MMC_PRECISION_FP8) && arch != MMC_ARCH_B4)
+        return fail(MMC_ERR_ARG, "MMC_PRECISION_FP8 is implemented for MMC_ARCH_B4 (BASELINE configs[4]): B0's late blocks run fused kernels without a separate project GEMM");
     *out = nullptr;
     if (!packed || nbytes < 16) return fail(MMC_ERR_WEIGHTS, "weights blob is empty");
     if (arch != MMC_ARCH_B0 && arch != MMC_ARCH_B4) return fail(MMC_ERR_ARG, "unsupported arch %d (MMC_ARCH_B0 or MMC_ARCH_B4)", arch);
@@ -427,6 +477,7 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     mmc_backbone* bb = new mmc_backbone();
     bb->device = device;
     bb->max_batch = max_batch;
+    bb->fp8 = (flags & MMC_PRECISION_FP8) != 0;
     const ArchDef AD = make_arch(arch);
     const bool is_b0 = arch == MMC_ARCH_B0;
     const int STEM_CH = AD.stem, HEAD_IN = AD.head_in, FEAT = AD.feat, NBLK = (int)AD.blocks.size();
@@ -516,6 +567,10 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
     const char* tail_env = getenv("MMC_TAIL");
     const bool tail_enabled = fuse_enabled && !(tail_env && tail_env[0] == '0');
     int H = IMG / 2;
+    // MMC_PRECISION_FP8: the project convs of the blocks whose OUTPUT is at most fp8_maxh pixels wide run on e4m3 operands.  Default 7
+    // (the 7x7 stage: the CPU study of the operand format puts feature cosine >= 0.997 there); MMC_FP8_MAXH=14 adds the 14x14 stages.
+    const int fp8_maxh = [] { const char* e = getenv("MMC_FP8_MAXH"); const int v = e ? atoi(e) : 7; return v < 7 ? 7 : v; }();
+    bb->fp8_from = NBLK;
     size_t max_act = (size_t)H * H * STEM_CH, max_exp = 0, max_dw = 0, max_pool = 0;
     int max_c = 0;
     for (int i = 0; i < NBLK; ++i) {
@@ -627,7 +682,8 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
                             if (k < B.cs) wep[off] = we[(size_t)n * B.cs + k];
                         }
             // B4: squeeze-excite + project per patch wherever proj_patch_kernel has the shape (blocks 6-15) and Cs fits its 32 slots
-            const bool b4_pp = fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
+            const bool fp8_blk = bb->fp8 && B.Ho <= fp8_maxh;
+            const bool b4_pp = !fp8_blk && fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
                                proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0);
             const bool pp_blk = (projse_enabled && i >= 3 && i <= 10) || (tail_enabled && i == 11) || b4_pp;
             if ((tail_enabled && i >= 12 && i <= 15 && B.cs == 48) || pp_blk) {
@@ -687,6 +743,29 @@ extern "C" int mmc_backbone_create(const void* packed, size_t nbytes, int arch, 
             TAKE(w, (size_t)B.d.cout * B.ce, nm);
             TAKE(b, B.d.cout, nm);
             TRY_OR_FREE(pack_pw(bb, &B.project, w, b, B.d.cout, B.ce, B.Ho <= 14 ? pick_nt(B.d.cout, true) : 0, 1.0 / LOG2E, 1.0));
+            if (bb->fp8 && B.Ho <= fp8_maxh) {
+                // e4m3 weights for pw_gemm_fp8_kernel: per-output-channel scale amax / 448 (the 1 / log2 e of the scaled domain rides in the
+                // scale), fragment f = channels 16 f .. +15, k-step of 128, lane (i, q) holds k = 128 ks + 32 q .. +31 of channel 16 f + i
+                Fp8Layer& L = B.p8;
+                L.N = B.d.cout; L.K = B.ce; L.KS128 = (B.ce + 127) / 128; L.NFp = ((B.d.cout + 15) / 16 + 6) / 7 * 7;
+                std::vector<uint8_t> w8((size_t)L.NFp * L.KS128 * 64 * 32, (uint8_t)0);
+                std::vector<float> sw((size_t)16 * L.NFp, 0.0f), bp((size_t)16 * L.NFp, 0.0f);
+                for (int nn = 0; nn < L.N; ++nn) {
+                    float amax = 0.f;
+                    for (int k = 0; k < L.K; ++k) amax = std::max(amax, std::fabs(w[(size_t)nn * L.K + k]));
+                    const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+                    sw[nn] = (float)(sc / LOG2E);
+                    bp[nn] = b[nn];
+                    for (int k = 0; k < L.K; ++k) {
+                        const int f = nn / 16, ii = nn % 16, ks = k / 128, qq = (k % 128) / 32, e = k % 32;
+                        w8[((((size_t)f * L.KS128 + ks) * 64) + qq * 16 + ii) * 32 + e] = e4m3_encode(w[(size_t)nn * L.K + k] / sc);
+                    }
+                }
+                TRY_OR_FREE(dev_upload(bb, &L.w8, w8));
+                TRY_OR_FREE(dev_upload(bb, &L.sw, sw));
+                TRY_OR_FREE(dev_upload(bb, &L.b, bp));
+                if (i < bb->fp8_from) bb->fp8_from = i;
+            }
             if (i == 0 && fuse_enabled && B.ce == 32 && B.d.cout == 16) {
                 // block 0's project conv as ONE MFMA fragment (16 outputs x 32 inputs) for mbconv_a_kernel PRE
                 std::vector<_Float16> wf(512, (_Float16)0.0f);
@@ -1206,6 +1285,11 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             a.res = B.skip ? x : nullptr;
             a.x_plane_rows = d_planar ? n * HWo : 0;
             STEP(nm, "thin_proj", launch_thin_proj(a, n, st));
+        } else if (B.p8.w8) {
+            Fp8GemmArgs fa{};
+            fa.X = ws.dwbuf; fa.M = n * HWo; fa.K = B.p8.K; fa.W8 = B.p8.w8; fa.KS128 = B.p8.KS128; fa.NFp = B.p8.NFp; fa.sw = B.p8.sw;
+            fa.bias = B.p8.b; fa.Y = y; fa.N = B.p8.N; fa.gate = ws.gate; fa.HW = HWo; fa.res = B.skip ? x : nullptr;
+            STEP(nm, "pw_gemm_fp8", launch_pw_gemm_fp8(fa, st));
         } else
         STEP(nm, gemm_label(B.project, n * HWo, EPI_LINEAR, true, B.skip), run_gemm(B.project, ws.dwbuf, n * HWo, y, EPI_LINEAR, ws.gate, HWo, B.skip ? x : nullptr, nullptr, st));
         snprintf(nm, sizeof nm, "b%d.out", i);

@@ -129,6 +129,45 @@ def test_b4_at_config_batch_size(synth_sd_b4):
         small.close()
 
 
+def test_b4_fp8_project_convs_on_e4m3_operands(synth_sd_b4):
+    """BASELINE.json configs[4] as stated: EfficientNet-B4 with fp8 (OCP e4m3) weights / activations on the CDNA4 fp8 MFMA
+    (precision="fp8": the squeeze-excite gated project convs of the 7x7 stage, per-output-channel weight scales, per-pixel
+    activation scales; pw_gemm_fp8_kernel).  Not in the reference.  Accuracy is reported and bounded by what the operand format
+    itself costs: the fp32 oracle re-run with exactly these operands quantised (tests/study_fp8.py) gives rel-L2 2.7e-2 .. 5.8e-2
+    and cosine >= 0.9983 on the image-like patches, 6.3e-2 .. 8.1e-2 / >= 0.9969 on white noise.  Gates: cosine >= 0.997
+    (image-like) / >= 0.995 (noise) against the fp32 oracle; rel-L2 within 1.3 x the emulation's + the fp16 path's own error.
+    Rows stay independent of batching."""
+    import torch
+    import study_fp8
+    from mermaid_classifier_amd.backbone import Backbone
+    from oracle import efficientnet_b0_ref as ref
+    g = np.load(GOLDEN / "backbone_b4_features.npz")
+    net = ref.EfficientNetB0Ref(synth_sd_b4, arch="b4")
+    sd = {k: v.numpy() for k, v in synth_sd_b4.items()}
+    bb = Backbone(sd, device=0, max_batch=4, precision="fp8")
+    bh = Backbone(sd, device=0, max_batch=4)
+    try:
+        outs = []
+        for kind, patches, want, cos_gate in (("natural", ref.natural_patches(4, seed=7), g["natural4"], 0.997),
+                                              ("noise", ref.synthetic_patches(4, seed=42), g["noise4"], 0.995)):
+            got, half = bb.extract(patches), bh.extract(patches)
+            outs.append(got)
+            with torch.no_grad():
+                emu = study_fp8.forward(net, ref.transformation(patches), "pixel", lambda k, i, h: k == "project" and h <= 7).numpy()
+            r, e, rh, c = rel_l2(got, want), rel_l2(emu, want), rel_l2(half, want), cosine(got, want)
+            print(f"b4 fp8 {kind}: rel-L2 {r} (operand-format emulation {e}, fp16 path {rh}) cos {c}")
+            assert np.all(c >= cos_gate), (kind, c)
+            assert np.all(r <= 1.3 * e + rh), (kind, r, e, rh)
+            assert not np.array_equal(got, half)          # the fp8 path really ran
+        both = bb.extract(np.concatenate([ref.natural_patches(4, seed=7), ref.synthetic_patches(4, seed=42)]))
+        assert np.array_equal(both, np.concatenate(outs))
+    finally:
+        bb.close()
+        bh.close()
+    with pytest.raises(ValueError):
+        Backbone({k: v for k, v in sd.items()}, device=0, max_batch=4, precision="int4")
+
+
 def test_batching_is_bitwise_invariant(backbone):
     """Rows are independent: any split of the same patches gives identical bits (ragged + max-batch)."""
     from oracle import efficientnet_b0_ref as ref

@@ -307,3 +307,18 @@ def test_golden_torchscript_archives_carry_no_reference_source_text():
         assert not [n for n in names if n.endswith(".debug_pkl")], pt
         for n in names:
             assert b"/root/reference" not in z.read(n), (pt, n)
+
+
+def test_fp8_e4m3_encoder_matches_an_independent_implementation():
+    """include/mmc.h mmc_fp8_e4m3_encode (the host-side quantiser of the fp8 project weights, BASELINE configs[4]) against
+    torch's float8_e4m3fn cast: round to nearest even, subnormals, saturation at +-448, zero below half the smallest subnormal."""
+    import torch
+    from mermaid_classifier_amd import _lib
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 100, 100000), rng.normal(0, 1, 100000), rng.normal(0, 0.01, 50000),
+                        np.array([0, 448, 449, 463.9, 464, 480, 1e9, -448, -500, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -10, 2.0 ** -6,
+                                  0.0145, -0.0, 17.0, 18.0, 19.0])]).astype(np.float32)
+    out = np.zeros(len(x), np.uint8)
+    _lib.check(_lib.lib().mmc_fp8_e4m3_encode(x.ctypes.data, out.ctypes.data, len(x)))
+    want = torch.from_numpy(x).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(out, want)

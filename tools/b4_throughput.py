@@ -14,12 +14,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp8"])
     a = ap.parse_args()
     import torch
     from mermaid_classifier_amd.backbone import Backbone
     from mermaid_classifier_amd.synthetic import synthetic_state_dict
     stats = {k: v.astype(np.float32) for k, v in np.load(ROOT / "tests/golden/synth_bn_stats_b4.npz").items()}
-    bb = Backbone(synthetic_state_dict(0, stats, arch="b4"), device=0, max_batch=a.batch)
+    bb = Backbone(synthetic_state_dict(0, stats, arch="b4"), device=0, max_batch=a.batch, precision=a.precision)
     p = torch.from_numpy(np.random.default_rng(42).integers(0, 255, (a.batch, 224, 224, 3), dtype=np.uint8)).cuda()
     f = torch.empty((a.batch, bb.feature_dim), dtype=torch.float32, device="cuda")
     for _ in range(3):
@@ -30,7 +31,7 @@ def main():
         bb.extract(p, out=f)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"B4 batch {a.batch}: {dt*1e3:.2f} ms/pass -> {a.batch/dt:.0f} patches/s ({a.batch/dt*3.0e9/1e12:.1f} TFLOP/s at 3.00 GFLOP/patch); "
+    print(f"B4 {a.precision} batch {a.batch}: {dt*1e3:.2f} ms/pass -> {a.batch/dt:.0f} patches/s ({a.batch/dt*3.0e9/1e12:.1f} TFLOP/s at 3.00 GFLOP/patch); "
           f"workspace {bb.workspace_bytes/2**30:.2f} GiB, lanes {bb.lanes}")
     per = defaultdict(float)
     prof = bb.profile(p, f)

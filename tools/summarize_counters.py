@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel SQ / TCC / TCP counter table from the PMC passes of tools/gpu.sh counters.
 
-  python tools/summarize_counters.py <round-tag> <dir with sq1/ sq2/ tcc/ fetch/ write/> [title suffix]
+  python tools/summarize_counters.py <round-tag> <dir with sq1/ sq2/ tcc/ fetch/ write/> [title suffix] [profiled command + what a launch covers]
 
 Writes profiles/<tag>_sq_counters.md.  Per launch (average over the launches of the run, kernels serialised by the
 profiler).  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over waves, so they are reported as
@@ -53,6 +53,8 @@ def load(d):
 def main():
     tag, base = sys.argv[1], sys.argv[2]
     suffix = sys.argv[3] if len(sys.argv) > 3 else ""
+    what = sys.argv[4] if len(sys.argv) > 4 else ("python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-passes 1` (tools/gpu.sh counters; one counter "
+                                                  "group per run; every launch covers one lane = 128 patches")
     passes = {p: load(f"{base}/{p}") for p in ("sq1", "sq2", "tcc", "fetch", "write")}
 
     def val(p, k, c):
@@ -62,9 +64,8 @@ def main():
     kernels = sorted(passes["sq1"][2], key=lambda k: -passes["sq1"][2][k][0])
     kernels = [k for k in kernels if passes["sq1"][2][k][0] > 0 and "rocclr" not in k and val("sq1", k, "SQ_WAVES") > 0]
     out = [f"# SQ / TCC / TCP counters per kernel launch ({tag}{suffix})", "",
-           "command per pass: `rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
-           "--no-cpu-baseline --profile-passes 1` (tools/gpu.sh counters; one counter group per run; every launch covers one "
-           "lane = 128 patches; kernels are serialised by the profiler, so durations are those of a kernel alone on the chip)", "",
+           "command per pass: `rocprofv3 --pmc <group> --output-format csv -- " + what +
+           "; kernels are serialised by the profiler, so durations are those of a kernel alone on the chip)", "",
            "Groups: sq1 = SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY "
            "SQ_INSTS_VALU; sq2 = SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES "
            "SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS; tcc = TCP_TCC_READ_REQ_sum TCC_HIT_sum "

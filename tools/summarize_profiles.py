@@ -28,9 +28,10 @@ def main():
     latest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
     rows = list(csv.DictReader(open(latest(f"{stats_dir}/*/*kernel_stats.csv"))))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
+    cmd = os.environ.get("SUMMARY_CMD", "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-passes 1 --spread-blocks 1` "
+                         "(passes of 256 patches, 2 lanes of 128: every launch covers 128 patches; both lanes running")
     out = [f"# rocprofv3 --kernel-trace --stats summary ({tag})", "",
-           "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 "
-           "--no-cpu-baseline --profile-passes 1` (13 passes of 256 patches, 2 lanes of 128: every launch covers 128 patches)", "",
+           "command: `rocprofv3 --kernel-trace --stats --output-format csv -- " + cmd + ")", "",
            f"total kernel time {total / 1e6:.2f} ms", "",
            "| kernel | calls | avg us | total ms | % |", "|---|---:|---:|---:|---:|"]
     for r in rows:
