@@ -1787,6 +1787,14 @@ __global__ __launch_bounds__(256) void mbconv_d_kernel(const _Float16* __restric
 #define T7_LDS (T7_OFF_STG + 8 * 16 * T7_PCS)
 static_assert(T7_LDS >= T7_OFF_PART + 32 * 48 * 4 && T7_LDS <= 163840, "tail7 LDS map");
 
+// 1: the squeeze-excite gate rides on the project's WEIGHT fragments (each wave scales the fragments it streams: 8 v_fma_mix per
+// fragment between the MFMAs, product in fp32, one rounding) instead of on the expanded tensor (a pass over ED[49][1152] between two
+// barriers: 3.7 k cycles per block).  Measured (round 3, build_variants via MMC_LIBRARY): the gate pass disappears but the project
+// grows from 12.6 k to 16-19.6 k cycles -- the extra vector instructions are not free in an MFMA phase that is also LDS- and
+// latency-bound at two waves per SIMD -- bench 229.3 k vs 231.3 k patches/s.  0 (the round-2 gate pass) stays the default.
+#ifndef T7_GATE_IN_WEIGHTS
+#define T7_GATE_IN_WEIGHTS 0
+#endif
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -1867,29 +1875,52 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             h8 bx[4], bn[4], wb[NF][4];
 #pragma unroll
             for (int pf = 0; pf < 4; ++pf) bx[pf] = *reinterpret_cast<const h8*>(bxp[pf]);
+            // gate values of the k-step's eight channels of this lane (A operand: lane (m, q) holds k = 32 ks + 8 q .. + 7), one step ahead
+            f4 gc0 = *reinterpret_cast<const f4*>(gate + 8 * q), gc1 = *reinterpret_cast<const f4*>(gate + 8 * q + 4), gn0, gn1;
+            auto gated = [&](const h8& w) -> h8 {
+                if (!T7_GATE_IN_WEIGHTS) return w;
+                const uint4 o = gate_h8(*reinterpret_cast<const uint4*>(&w), gc0, gc1);   // fp32 product, one rounding (wait states padded inside)
+                return *reinterpret_cast<const h8*>(&o);
+            };
             auto step = [&](int ks, const h8 (&wset)[3][4], int d) {
                 const int kn = ks + 1 < KSC ? ks + 1 : KSC - 1;   // last step re-reads itself (unused)
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+                if (T7_GATE_IN_WEIGHTS) {
+                    gn0 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q);
+                    gn1 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q + 4);
+                }
+                h8 wg[NF];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) wg[i] = gated(wset[i][d]);
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
                     for (int pf = 0; pf < 4; ++pf)
-                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wset[i][d], bx[pf], acc[i][pf], 0, 0, 0);
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[i], bx[pf], acc[i][pf], 0, 0, 0);
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+                gc0 = gn0; gc1 = gn1;
             };
             auto stepb = [&](int ks, int d) {
                 const int kn = ks + 1 < KSC ? ks + 1 : KSC - 1;
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) bn[pf] = *reinterpret_cast<const h8*>(bxp[pf] + 64 * kn);
+                if (T7_GATE_IN_WEIGHTS) {
+                    gn0 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q);
+                    gn1 = *reinterpret_cast<const f4*>(gate + 32 * kn + 8 * q + 4);
+                }
+                h8 wg[NF];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) wg[i] = gated(wb[i][d]);
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
                     for (int pf = 0; pf < 4; ++pf)
-                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[i][d], bx[pf], acc[i][pf], 0, 0, 0);
+                        acc[i][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wg[i], bx[pf], acc[i][pf], 0, 0, 0);
 #pragma unroll
                 for (int pf = 0; pf < 4; ++pf) bx[pf] = bn[pf];
+                gc0 = gn0; gc1 = gn1;
             };
 #pragma unroll 1
             for (int k0 = 0; k0 + 8 <= KSC; k0 += 8) {
@@ -2214,6 +2245,9 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         proj_prefetch(wproj, bproj, 24, nf0, nfn, lane, q, pbias, wo, wa);
         T7_BAR();
         if (clk_on) tkk[2] = (long long)__builtin_readcyclecounter();
+        if (T7_GATE_IN_WEIGHTS) {
+            if (tid < 96) gate[672 + tid] = 0.f;   // k-steps 21..23 are zero padding: their gate values must be finite
+        } else
         if (tid < 504) {   // 84 groups of 8 channels x 6 pixel residues: the gate values stay in registers (see the blocks' gate pass)
             const int r6 = tid / 84, oc = tid - 84 * r6;
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
@@ -2852,6 +2886,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // A thread keeps ONE group of 8 channels (its 8 gate values in registers) and walks every third pixel: 144 groups x 3 = 432
         // threads.  (One (pixel, group) element per thread and step re-read the 32 bytes of gate values for every 16 bytes of
         // data: the pass is LDS traffic, and two thirds of it was gate.)
+        if (!T7_GATE_IN_WEIGHTS)
         if (tid < 432) {
             const int r3 = tid >= 288 ? 2 : (tid >= 144 ? 1 : 0), oc = tid - 144 * r3;
             const f4 g0 = *reinterpret_cast<const f4*>(gate + oc * 8);
@@ -2872,7 +2907,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
             }
         }
-        T7_BAR();
+        if (!T7_GATE_IN_WEIGHTS) T7_BAR();   // (with the gate on the weights nothing happens between FC2's barrier and the project)
         T7_TICK();
         // ---------------- project + bias (+ residual) ----------------
         proj_run(W.wproj, 36, wide ? 1 : 0, nf0, nfn, lane, m, q, pixc, pbias, wo, wa);

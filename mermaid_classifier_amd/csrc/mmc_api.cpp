@@ -552,9 +552,12 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
     bb->mid14 = mid14_enabled;
     bb->mid14_last = mid14_mode == 1 ? 10 : 8;
     { const char* e = getenv("MMC_MID14_B11"); bb->mid14_b11 = mid14_mode == 1 && e && e[0] == '1'; }   // block 11's front half (stride 2) too: measured equal (35.7 vs 33.0 us), opt-in
-    // MMC_MID14M=1 (default 0): blocks 6..10 on mid14m_kernel -- depthwise conv on 4x4x4 MFMA blocks (block = channel), wave-private channel
-    // groups, one barrier per kernel; measured equal to mid14_kernel so far, kept as a tested variant
-    const bool mid14m_enabled = mid14_enabled && [] { const char* e = getenv("MMC_MID14M"); return e && e[0] == '1'; }();
+    // MMC_MID14M (default 2): mid14m_kernel -- depthwise conv on 4x4x4 MFMA blocks (block = channel), wave-private channel groups, one
+    // barrier per kernel -- 2: on the 5x5 blocks 8..10 (13-24 % ahead of mid14_kernel alone on the chip, one workgroup per patch: bench
+    // 228.4 k vs 227.1 k patches/s), 1: on blocks 6..10 (the 3x3 blocks are equal alone and lose in the bench), 0: mid14_kernel everywhere
+    // (MMC_MID14M=2: only the 5x5 blocks 8..10, where it is 13-24 % ahead alone on the chip; the 3x3 blocks stay on mid14_kernel)
+    const int mid14m_mode = [] { const char* e = getenv("MMC_MID14M"); return e ? atoi(e) : 2; }();
+    const bool mid14m_enabled = mid14_enabled && mid14m_mode >= 1;
     // MMC_TAIL_DW4=1 (default 0): tail7_kernel's blocks 12..15 with the depthwise conv on 4x4x4 MFMA blocks, fused with the expand into one
     // wave-private phase.  Parity-tested; measured 44-45 k cycles per block for expand + depthwise against 40.6 k for the round-2 phases
     // (45 % fewer vector instructions, but the 4x4x4 MFMAs hold the issue port half their time and the phase does not
@@ -634,7 +637,7 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp4, dp4));
             }
-            if (((mid14m_enabled && i >= 6 && i <= 10 && H == 14) || (tail_dw4 && tail_enabled && i >= 12 && i <= 15 && H == 7)) && B.d.s == 1 && B.ce % 16 == 0) {
+            if (((mid14m_enabled && i >= (mid14m_mode == 2 ? 8 : 6) && i <= 10 && H == 14) || (tail_dw4 && tail_enabled && i >= 12 && i <= 15 && H == 7)) && B.d.s == 1 && B.ce % 16 == 0) {
                 // Depthwise on the matrix pipe (mid14m_kernel, v_mfma_f32_4x4x4_16B_f16: 16 independent blocks = 16 channels).  A operand
                 // of block c, kernel row ky, input quad h (columns x0 - 2 + 4h .. +3 of an output tile x0 .. x0+3): the Toeplitz slice
                 // A[i][k] = w[c][ky][k - i + 4h - 2 + R] (zero outside 0 .. K-1), lane 4 blk + i holding k = 0 .. 3, block blk = channel
@@ -1151,7 +1154,7 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             ma.X = x; ma.wexp = B.exp_frag; ma.bexp = B.expand.b; ma.dwp = B.t_dwp4; ma.bdw = B.dw_b; ma.D = ws.dwbuf;
             ma.pool = ws.pool_part; ma.B = n; ma.Cin = B.d.cin; ma.Ce = B.ce; ma.ks = B.d.k;
             ma.dwdiag = (B.d.s == 1) ? B.dw_diag : nullptr;
-            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (ma.dwdiag ? 2 : (B.d.s == 2 ? 7 : 4)); }
+            { const char* e = getenv("MMC_MID14_SPLIT"); ma.nsplit = e ? atoi(e) : (ma.dwdiag ? 1 : (B.d.s == 2 ? 7 : 4)); }
             ma.stride = B.d.s;
             if (bb->mid_clk && i == 10) ma.dbg_clk = bb->mid_clk + (size_t)(&ws - bb->lanes) * bb->lane_cap * 128;
             nparts = 1;
