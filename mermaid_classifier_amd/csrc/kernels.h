@@ -153,6 +153,7 @@ struct MbtArgs {
     float* pool;              // [B][tiles][Ce]
     int B, H, Cin, Ce, ks;
     int stride;               // 1 (b2, b4: D is [B][H][H][Ce]) or 2 (b3, b5: D is [B][H/2][H/2][Ce], mbt2_kernel)
+    const _Float16* dwtoe;    // optional [Ce/16][ks][2][64][4]: Toeplitz depthwise fragments -> mbt4_kernel (5x5 stride 1 at 28x28)
 };
 int launch_mbt(const MbtArgs& a, hipStream_t st);
 int thin_proj_has(int ksteps);                          // 1 when launch_thin_proj has an instantiation for this many k-steps

@@ -3486,13 +3486,15 @@ __global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
             }
 #endif
             // the tile [56 pixels][32 B] leaves as 112 sixteen-byte vectors: lane L takes vectors L and L + 64 (the last strip has 56)
+            // (lanes past the last vector repeat it: no store behind a branch -- a conditional store makes the compiler wait for
+            // vmcnt(0), i.e. for the stores themselves, at the next use of a prefetched operand)
             constexpr int NV = YT == 3 ? 56 : 112;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int vi = lane + 64 * r;
                 if (64 * r >= NV) break;
-                const uint4 o = *reinterpret_cast<const uint4*>(TW + (vi < NV ? vi : 0) * 16);
-                if (vi < NV) *reinterpret_cast<uint4*>(dgb + (size_t)(56 * YT + (vi >> 1)) * (CE * 2) + 16 * (vi & 1)) = o;
+                const int v0 = lane + 64 * r, vi = v0 < NV ? v0 : NV - 1;
+                const uint4 o = *reinterpret_cast<const uint4*>(TW + vi * 16);
+                *reinterpret_cast<uint4*>(dgb + (size_t)(56 * YT + (vi >> 1)) * (CE * 2) + 16 * (vi & 1)) = o;
             }
         };
         {
@@ -3910,6 +3912,194 @@ __global__ __launch_bounds__(512) void mbt_kernel(MbtArgs a)
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 10; ++w) s += pred[w * CH + tid];
+        a.pool[((size_t)b * gridDim.x + tile) * CE + chunk * CH + tid] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// mbt4_kernel: mbt_kernel's 5x5 stride-1 layer at 28x28 (b4; B4's b7..b9) with the DEPTHWISE CONV ON THE MATRIX PIPE
+// (v_mfma_f32_4x4x4_16B_f16, block = channel: see mid14m_kernel).  Same workgroup = (patch, 14 x 28 output tile, chunk of 48
+// channels), same expand (window of 18 x 28 positions, pixel fragments straight into registers, un-swapped MFMA: a lane gets
+// four consecutive positions of one channel = ONE aligned quad of a window row, 28 being a multiple of 4) -- but the quad goes
+// to a PLANAR image E[48 channels][18 rows][28 columns] (64-byte rows, 1160 bytes per channel: the 8-byte stores of 16 channels
+// and the 8-byte reads of 8 channels x 4 rows are both conflict-free), rows outside the image as zeros, and the depthwise phase is
+// 24 items = 3 channel groups x 4 strips of four output rows x 2 column halves, three per wave: 5 kernel rows x (4 quad reads +
+// 7 MFMAs: output tiles at columns -2, 2, 6, 10 of the half, the zero border quad skipped) -> SiLU -> v_permlane16_swap ->
+// wave-private [56 pixels][16 channels] tile -> 16-byte stores.  The 630 v_dot2c of a depthwise thread become 35 MFMAs per item.
+// Template: CKS k-steps of the block input, CE expanded channels.
+// ---------------------------------------------------------------------------------------------
+template <int CKS, int CE>
+__global__ __launch_bounds__(512, 4) void mbt4_kernel(MbtArgs a)
+{
+    constexpr int HIMG = 28, R = 2, KSD = 5, NROWS = 18, WW = 28, CH = 48, NPOS = NROWS * WW, NPF = 32;
+    constexpr int ERS = 64, ECS = 1160;            // planar row / channel stride (18 x 64 + 8: the 8 spare bytes take masked stores)
+    constexpr int TREG = 56 * 32;                  // a wave's transpose tile [4 rows x 14 pixels][16 channels]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* E = smem;                                            // [48][ECS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* TW = smem + CH * ECS + wave * TREG;
+    float* pred = reinterpret_cast<float*>(smem + CH * ECS + 8 * TREG);   // [8 regions][48]
+    const int m = lane & 15, q = lane >> 4;
+    const int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const int oy0 = 14 * tile;
+    const int Cin = a.Cin;
+    const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HIMG * HIMG * Cin;
+    const GLOBAL_AS _Float16* wexp = sgpr_ptr<_Float16>(a.wexp);
+    const GLOBAL_AS _Float16* dwt = sgpr_ptr<_Float16>(a.dwtoe);
+    // ---------------- expand ----------------
+    {
+        u4v xr[4][CKS];
+        int eoff[4];      // byte offset of this lane's quad inside a channel's planar image (or the spare bytes)
+        bool okq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = 16 * (wave + 8 * i) + m;
+            const int r = (p * 2341) >> 16, c = p - r * WW;              // p / 28 (exact below 896)
+            const int iy = oy0 - R + r;
+            const bool ok = p < NPOS && iy >= 0 && iy < HIMG;
+            const int row = ok ? iy * HIMG + c : 0;
+            const int pq = 16 * (wave + 8 * i) + 4 * q;                  // this lane's output quad: positions pq .. pq+3 of one window row
+            const int qr = (pq * 2341) >> 16, qc = pq - qr * WW;
+            const int qy = oy0 - R + qr;
+            okq[i] = pq < NPOS && qy >= 0 && qy < HIMG;
+            eoff[i] = pq < NPOS ? qr * ERS + qc * 2 : NROWS * ERS;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) {
+                const int kk = 32 * ks + 8 * q;
+                xr[i][ks] = gload<u4v>(xg, (unsigned)((row * Cin + (kk < Cin ? kk : Cin - 8)) * 2));
+            }
+        }
+        h8 wa[3][CKS];
+        float ba[3];
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) {
+            const int nfg = 3 * chunk + nf;
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) wa[nf][ks] = gload<h8>(wexp, (unsigned)(((nfg * CKS + ks) * 64 + lane) * 16));
+            ba[nf] = a.bexp[16 * nfg + m];
+        }
+        PIN_VMEM();
+        f4 ba4[3];
+#pragma unroll
+        for (int nf = 0; nf < 3; ++nf) ba4[nf] = f4{ba[nf], ba[nf], ba[nf], ba[nf]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h8 xb[CKS];
+#pragma unroll
+            for (int ks = 0; ks < CKS; ++ks) xb[ks] = *reinterpret_cast<const h8*>(&xr[i][ks]);
+            float t[12];
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[0], wa[nf][0], ba4[nf], 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < CKS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], wa[nf][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[4 * nf + j] = acc[j];
+            }
+            silu_scaled_staged(t);
+            const uint32_t mk = okq[i] ? 0xffffffffu : 0u;   // rows outside the image are the depthwise conv's zero padding
+#pragma unroll
+            for (int nf = 0; nf < 3; ++nf) {
+                const u2v o = {cvt_pk_f16(t[4 * nf], t[4 * nf + 1]) & mk, cvt_pk_f16(t[4 * nf + 2], t[4 * nf + 3]) & mk};
+                *reinterpret_cast<u2v*>(E + (16 * nf + m) * ECS + eoff[i]) = o;
+            }
+        }
+    }
+    T7_BAR();
+    // ---------------- depthwise on 4x4x4 MFMA blocks ----------------
+    {
+        const int blk = lane >> 2, n = lane & 3;
+        const int c = 2 * (blk & 3) + ((blk >> 2) & 1) + 8 * (blk >> 3);     // channel of the group this lane's block holds (mid14m_kernel)
+        const bool oddrow = (blk >> 2) & 1;
+        const int yt = wave & 3, xh = wave >> 2;                               // this wave's region: output rows 4 yt .. +3, columns 14 xh .. +13
+        const int nn = (yt == 3 && n >= 2) ? 1 : n;                           // strip 3 has rows 12, 13 only: lanes n >= 2 repeat row 13
+        const bool rowok = !(yt == 3 && n >= 2);
+        const unsigned char* dld = E + c * ECS + (4 * yt + nn) * ERS + 24 * xh;   // + 16 g * ECS + ky * ERS + 8 * local quad (quads 0..3 / 3..6)
+        unsigned char* tst = TW + (n * 14 + (oddrow ? 7 : 0)) * 32 + (c >> 1) * 4;
+        // the tile's 112 (strip 3: 56) sixteen-byte vectors leave through lanes L and L + 64: pixel tp = v >> 1 -> row tp / 14, column tp % 14
+        // (lanes past the last vector repeat it -- same bytes to the same address: a store behind a branch makes the compiler wait for
+        // vmcnt(0), i.e. for the previous item's stores to reach memory, before the next item's first MFMA)
+        const int nv = yt == 3 ? 56 : 112;
+        unsigned goff[2], toff[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int v0 = lane + 64 * rr, vi = v0 < nv ? v0 : nv - 1, tp = vi >> 1;
+            const int tr = (tp * 147) >> 11, tx = tp - 14 * tr;
+            toff[rr] = (unsigned)(vi * 16);
+            goff[rr] = (unsigned)((((oy0 + 4 * yt + tr) * HIMG + 14 * xh + tx) * CE + chunk * CH) * 2 + 16 * (vi & 1));
+        }
+        unsigned char* dgb = reinterpret_cast<unsigned char*>(a.D + (size_t)b * HIMG * HIMG * CE);
+        u2v ta[KSD][2], tan[KSD][2];
+        float bd, bdn;
+        auto request_t = [&](int g, u2v (&w2)[KSD][2], float& b2) {
+            const int G = 3 * chunk + g;
+#pragma unroll
+            for (int ky = 0; ky < KSD; ++ky)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) w2[ky][h] = gload<u2v>(dwt, (unsigned)((((G * KSD + ky) * 2 + h) * 64 + lane) * 8));
+            b2 = a.bdw[16 * G + c];
+        };
+        request_t(0, tan, bdn);
+        auto item = [&](int g, auto xh_tag) __attribute__((always_inline)) {
+            constexpr int XH = decltype(xh_tag)::value;
+#pragma unroll
+            for (int ky = 0; ky < KSD; ++ky) { ta[ky][0] = tan[ky][0]; ta[ky][1] = tan[ky][1]; }
+            bd = bdn;
+            request_t(g + 1 < 3 ? g + 1 : g, tan, bdn);
+            PIN_VMEM();
+            const f4 bdv = {bd, bd, bd, bd};
+            f4 acc[4];
+            const unsigned char* rb = dld + 16 * g * ECS;
+#pragma unroll
+            for (int ky = 0; ky < KSD; ++ky) {
+                h4 ql[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ql[k] = *reinterpret_cast<const h4*>(rb + ky * ERS + 8 * k);
+                const h4 a0 = __builtin_bit_cast(h4, ta[ky][0]), a1 = __builtin_bit_cast(h4, ta[ky][1]);
+                if (XH == 0) {   // tiles at columns -2, 2, 6, 10: quad t with the h = 1 slice, quad t - 1 with the h = 0 slice (tile 0's left quad is the zero border)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, ql[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, ql[t - 1], acc[t], 0, 0, 0);
+                } else {         // tiles at columns 14, 18, 22, 26: local quad t (= quad 3 + t) with h = 0, local quad t + 1 with h = 1 (tile 3's right quad is the zero border)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, ql[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, ql[t + 1], acc[t], 0, 0, 0);
+                }
+            }
+            float v[14];
+#pragma unroll
+            for (int x = 0; x < 14; ++x) v[x] = XH == 0 ? acc[(x + 2) >> 2][(x + 2) & 3] : acc[x >> 2][x & 3];
+            silu_scaled_staged(v);
+            float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) + ((v[8] + v[9]) + (v[10] + v[11])) + (v[12] + v[13]);
+            s = quad_sum(rowok ? s : 0.f);
+            if (n == 0) pred[(2 * yt + xh) * CH + 16 * g + c] = s;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                float lo = v[j], hi = v[7 + j];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+                *reinterpret_cast<uint32_t*>(tst + j * 32) = cvt_pk_f16(lo, hi);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const uint4 o = *reinterpret_cast<const uint4*>(TW + toff[rr]);
+                *reinterpret_cast<uint4*>(dgb + goff[rr] + 32 * g) = o;
+            }
+        };
+        if (xh == 0) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) item(g, std::integral_constant<int, 0>{});
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) item(g, std::integral_constant<int, 1>{});
+        }
+    }
+    T7_BAR();
+    if (tid < CH) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += pred[w * CH + tid];
         a.pool[((size_t)b * gridDim.x + tile) * CE + chunk * CH + tid] = s;
     }
 }
@@ -5165,6 +5355,21 @@ static int launch_mbt_t(const MbtArgs& a, hipStream_t st)
     return 0;
 }
 
+template <int CKS, int CE>
+static int launch_mbt4_t(const MbtArgs& a, hipStream_t st)
+{
+    const int lds = 48 * 1160 + 8 * 56 * 32 + 8 * 48 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbt4_kernel<CKS, CE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((mbt4_kernel<CKS, CE>), dim3(2, CE / 48, a.B), dim3(512), lds, st, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 template <int KSD, int CKS, int CE, int HIMG>
 static int launch_mbt2_t(const MbtArgs& a, hipStream_t st)
 {
@@ -5193,6 +5398,8 @@ int launch_mbt(const MbtArgs& a, hipStream_t st)
         return -5;
     }
     if (a.H == 56 && a.ks == 3 && a.Cin == 24 && a.Ce == 144) return launch_mbt_t<3, 1, 144, 56>(a, st);   // b2
+    if (a.dwtoe && a.H == 28 && a.ks == 5 && a.Cin == 40 && a.Ce == 240) return launch_mbt4_t<2, 240>(a, st);   // b4, depthwise on 4x4x4 MFMA blocks
+    if (a.dwtoe && a.H == 28 && a.ks == 5 && a.Cin == 56 && a.Ce == 336) return launch_mbt4_t<2, 336>(a, st);   // B4 b7-b9
     if (a.H == 28 && a.ks == 5 && a.Cin == 40 && a.Ce == 240) return launch_mbt_t<5, 2, 240, 28>(a, st);   // b4
     if (a.H == 56 && a.ks == 3 && a.Cin == 32 && a.Ce == 192) return launch_mbt_t<3, 1, 192, 56>(a, st);   // B4 b3-b5
     if (a.H == 28 && a.ks == 5 && a.Cin == 56 && a.Ce == 336) return launch_mbt_t<5, 2, 336, 28>(a, st);   // B4 b7-b9

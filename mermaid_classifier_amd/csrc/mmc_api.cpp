@@ -564,7 +564,9 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
     // overlap its matrix and vector halves at two waves per SIMD), so it stays opt-in.
     const bool tail_dw4 = [] { const char* e = getenv("MMC_TAIL_DW4"); return e && e[0] == '1'; }();
     const char* mbt_env = getenv("MMC_MBT");
-    const bool mbt_enabled = (fuse_enabled || fuse_generic_early) && !(mbt_env && mbt_env[0] == '0');   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
+    const bool mbt_enabled = (fuse_enabled || fuse_generic_early) && !(mbt_env && mbt_env[0] == '0');
+    // MMC_MBT4 (default 1): the 5x5 stride-1 layers at 28x28 (b4; B4's b7..b9) on mbt4_kernel (depthwise conv on 4x4x4 MFMA blocks)
+    const bool mbt4_enabled = [] { const char* e = getenv("MMC_MBT4"); return !(e && e[0] == '0'); }();   // default since the pair-interleaved tile: b2 66 vs 78.5 us, b4 42.6 vs 59.5
     bb->mbt = mbt_enabled;
     { const char* e = getenv("MMC_MBT2"); bb->mbt2 = mbt_enabled && !(e && e[0] == '0'); }
     const char* tail_env = getenv("MMC_TAIL");
@@ -637,7 +639,7 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_dwp4, dp4));
             }
-            if (((mid14m_enabled && i >= (mid14m_mode == 2 ? 8 : 6) && i <= 10 && H == 14) || (tail_dw4 && tail_enabled && i >= 12 && i <= 15 && H == 7)) && B.d.s == 1 && B.ce % 16 == 0) {
+            if (((mid14m_enabled && i >= (mid14m_mode == 2 ? 8 : 6) && i <= 10 && H == 14) || (mbt4_enabled && mbt_enabled && H == 28 && B.d.k == 5 && mbt_has(H, B.d.k, B.d.s, B.d.cin, B.ce)) || (tail_dw4 && tail_enabled && i >= 12 && i <= 15 && H == 7)) && B.d.s == 1 && B.ce % 16 == 0) {
                 // Depthwise on the matrix pipe (mid14m_kernel, v_mfma_f32_4x4x4_16B_f16: 16 independent blocks = 16 channels).  A operand
                 // of block c, kernel row ky, input quad h (columns x0 - 2 + 4h .. +3 of an output tile x0 .. x0+3): the Toeplitz slice
                 // A[i][k] = w[c][ky][k - i + 4h - 2 + R] (zero outside 0 .. K-1), lane 4 blk + i holding k = 0 .. 3, block blk = channel
@@ -1144,10 +1146,12 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             MbtArgs ta{};
             ta.X = x; ta.wexp = B.exp_frag; ta.bexp = B.expand.b; ta.dwp = B.t_dwp; ta.bdw = B.dw_b; ta.D = ws.dwbuf;
             ta.pool = ws.pool_part; ta.B = n; ta.H = B.H; ta.Cin = B.d.cin; ta.Ce = B.ce; ta.ks = B.d.k; ta.stride = B.d.s;
+            ta.dwtoe = (B.d.s == 1 && B.H == 28 && B.d.k == 5) ? B.dw_diag : nullptr;
             nparts = B.d.s == 2 ? (B.Ho / 7) * (B.Ho / 14) : (B.H / 14) * (B.H / 28);
             snprintf(nm, sizeof nm, "b%d.mbconv", i);
             char ml[48];   // the instantiation's template arguments, as rocprofv3 names it
             snprintf(ml, sizeof ml, "%s<%d,%d,%d,%d>", B.d.s == 2 ? "mbt2" : "mbt", B.d.k, (B.d.cin + 31) / 32, B.ce, B.H);
+            if (ta.dwtoe) snprintf(ml, sizeof ml, "mbt4<%d,%d>", (B.d.cin + 31) / 32, B.ce);
             STEP(nm, ml, launch_mbt(ta, st));
         } else if (B.fused && bb->mid14 && ((i >= 6 && i <= bb->mid14_last) || (i == 11 && bb->mid14_b11)) && B.t_dwp && B.exp_frag) {
             Mid14Args ma{};

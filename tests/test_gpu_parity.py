@@ -387,7 +387,7 @@ def test_full_batch_size_independent_properties(checkpoint_path, golden_backbone
     bb.close()
 
 
-@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_B11", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MID14_B11=1", "MMC_MID14M=1", "MMC_MID14M=0", "MMC_TAIL_DW4=1", "MMC_MB1", "MMC_MBT", "MMC_MBT2", "MMC_THIN_PROJ", "MMC_B1_PLANAR", "MMC_GRAPH",
+@pytest.mark.parametrize("knob", ["MMC_FUSE_B0", "MMC_SE_SMALL", "MMC_PROJSE", "MMC_TAIL_B11", "MMC_TAIL_FULL", "MMC_TAIL", "MMC_MB_DOT2", "MMC_MID14", "MMC_MID14=2", "MMC_MID14_B11=1", "MMC_MID14M=1", "MMC_MID14M=0", "MMC_MBT4=0", "MMC_TAIL_DW4=1", "MMC_MB1", "MMC_MBT", "MMC_MBT2", "MMC_THIN_PROJ", "MMC_B1_PLANAR", "MMC_GRAPH",
                                   "MMC_LANES"])
 def test_every_schedule_variant_meets_the_same_gates(checkpoint_path, golden_backbone, knob, monkeypatch):
     """Each fusion has an environment switch (the separate kernels stay in the library as the reference
