@@ -4641,6 +4641,16 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     //      row segment starts on a dword (6*(16tx-2) bytes); 37 rows x 31 dwords (41 pixels), one dword per thread-step
     const int icol0 = 2 * (ox0 - 2);                 // may be -4 for the leftmost tiles (those pixels are never used)
     constexpr int cshift = 2;                        // staged column of window column 0's first input pixel: 2 (ox0 - 1) - icol0
+    // Everything the later phases read from global memory is requested HERE, in front of the input tile (round 3: the stem weights and
+    // biases used to be loaded behind the first barrier and the depthwise biases behind the second -- one exposed L2 round trip each).
+    h8 wf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
+    f4 bsv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bsv[t] = *reinterpret_cast<const f4*>(bias + q * 8 + t * 4);
+    const f4 bdw0 = *reinterpret_cast<const f4*>(bdw + (tid & 3) * 8), bdw1 = *reinterpret_cast<const f4*>(bdw + (tid & 3) * 8 + 4);
+    const float wl0 = Wdw[tid], wl1 = Wdw[256 + (tid & 31)];
     {
         const uint8_t* img = patches + (size_t)b * (224 * 224 * 3);
         const int iy0 = 2 * wy0;
@@ -4651,23 +4661,52 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
         // instructions per byte on pixel/channel bookkeeping).  Same values either way.
         const bool interior = tx < 6 && ty < 6;   // workgroup-uniform
         if (interior) {
-            for (int i = tid; i < rows * 31; i += 256) {
+            // ALL of a thread's dwords are requested before the first is converted (round 3: the loop used to be load -> s_waitcnt
+            // vmcnt(0) -> convert -> store, four to five exposed HBM round trips in front of everything else the workgroup does).
+            // Unconditional loads from clamped addresses: a branch around a load makes the compiler wait for it at once.  Dwords left
+            // of the image (boff < 0, leftmost tiles) and past the last row hold some other pixel's bytes: never used / never stored.
+            constexpr int NIT = (37 * 31 + 255) / 256;
+            uint32_t wd[NIT];
+            const int nd = rows * 31;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i0 = tid + 256 * it, i = i0 < nd ? i0 : nd - 1;
                 const int r = i / 31, d = i - r * 31;
                 const int boff = icol0 * 3 + d * 4;
-                uint32_t word = 0;
-                if (boff >= 0) word = *reinterpret_cast<const uint32_t*>(img + (size_t)(iy0 + r) * 672 + boff);   // (boff < 0: columns never used)
+                wd[it] = *reinterpret_cast<const uint32_t*>(img + (size_t)(iy0 + r) * 672 + (boff >= 0 ? boff : 0));
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + 256 * it;
+                const int r = i / 31, d = i - r * 31;
+                const uint32_t word = wd[it];
                 h4 v = {(_Float16)((float)(word & 0xffu) - 128.0f), (_Float16)((float)((word >> 8) & 0xffu) - 128.0f),
                         (_Float16)((float)((word >> 16) & 0xffu) - 128.0f), (_Float16)((float)(word >> 24) - 128.0f)};
-                *reinterpret_cast<h4*>(tile + r * SD_ROWH + d * 4) = v;   // (row stride 128 halves: the 124th half is spare)
+                if (i < nd) *reinterpret_cast<h4*>(tile + r * SD_ROWH + d * 4) = v;   // (row stride 128 halves: the 124th half is spare)
             }
-        } else
-        for (int i = tid; i < rows * 31; i += 256) {
+        } else {
+        // right / bottom edge tiles: the same, all requests first (unconditional, clamped to the image; what lies outside is replaced
+        // by the padding values below)
+        constexpr int NIT = (37 * 31 + 255) / 256;
+        uint32_t wd[NIT];
+        const int nd = rows * 31;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i0 = tid + 256 * it, i = i0 < nd ? i0 : nd - 1;
+            const int r = i / 31, d = i - r * 31;
+            const int iy = iy0 + r < 224 ? iy0 + r : 223;
+            int boff = icol0 * 3 + d * 4;
+            boff = boff < 0 ? 0 : (boff > 668 ? 668 : boff);
+            wd[it] = *reinterpret_cast<const uint32_t*>(img + (size_t)iy * 672 + boff);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            if (i >= nd) break;
             const int r = i / 31, d = i - r * 31;
             const int iy = iy0 + r;
-            const int boff = icol0 * 3 + d * 4;      // byte offset in the image row (multiple of 4, may be negative)
-            uint32_t word = 0;
+            const uint32_t word = wd[it];
             const bool row_ok = iy < 224;
-            if (row_ok && boff >= 0 && boff < 672) word = *reinterpret_cast<const uint32_t*>(img + (size_t)iy * 672 + boff);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int bb = d * 4 + e;             // byte inside the staged row (0..123)
@@ -4679,7 +4718,9 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
                 if (bb < 123) tile[r * SD_ROWH + bb] = (_Float16)v;
             }
         }
-        for (int i = tid; i < 9 * 32; i += 256) wl[i] = Wdw[i];
+        }
+        wl[tid] = wl0;
+        if (tid < 32) wl[256 + tid] = wl1;
         if (tx == 0 || ty == 0 || tx == 6 || ty == 6)   // border tiles: zero the window positions outside the image
             for (int pz = tid; pz < P; pz += 256) {
                 const int py = pz / SD_WIN, px = pz - py * SD_WIN;
@@ -4693,12 +4734,6 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     __syncthreads();
     // ---- phase 1: stem conv on the window -> E[p][32] ----
     {
-        h8 wf[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) wf[t] = *reinterpret_cast<const h8*>(w + (t * 16 + m) * 32 + q * 8);
-        f4 bsv[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bsv[t] = *reinterpret_cast<const f4*>(bias + q * 8 + t * 4);
         constexpr int MTn = (P + 15) >> 4;
         for (int mt = wave; mt < MTn; mt += 4) {
             const int p = mt * 16 + m;
@@ -4746,12 +4781,8 @@ __global__ __launch_bounds__(256) void stem_dw_kernel(const uint8_t* __restrict_
     const int oyl = s >> 2, oxl = (s & 3) * 4;
     const int oy = oy0 + oyl, ox = ox0 + oxl;
     float bs[8];
-    {
-        const f4 b0 = *reinterpret_cast<const f4*>(bdw + cg * 8);
-        const f4 b1 = *reinterpret_cast<const f4*>(bdw + cg * 8 + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { bs[j] = b0[j]; bs[4 + j] = b1[j]; }
-    }
+    for (int j = 0; j < 4; ++j) { bs[j] = bdw0[j]; bs[4 + j] = bdw1[j]; }   // (cg = tid & 3: requested at the top of the kernel)
     float acc[4][8];
     const unsigned char* ebase = E + ((oyl * SD_WIN + oxl) * SD_ES + cg * 16);   // window position (oyl + ky, oxl + xr) = output (oy - 1 + ky, ox - 1 + xr)
 #pragma unroll
