@@ -384,6 +384,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
         }
         return;
     }
+    // skip-connection operands: ALL of them requested before the first is used (unconditional, clamped addresses) -- inside the
+    // row / channel conditions below every load was followed by its own s_waitcnt vmcnt(0): MT x NT exposed round trips per workgroup
+    h4 rres[MT][NT];
+    if (RES) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = cbase + 4 * t;
+                rres[i][t] = *reinterpret_cast<const h4*>(res + (size_t)(rok[i] ? row[i] : 0) * N + (c < N ? c : 0));
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         if (!rok[i]) continue;
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
                     for (int j = 0; j < 4; ++j) v[j] = silu_scaled(v[j]);
                 }
                 if (RES) {
-                    const h4 r = *reinterpret_cast<const h4*>(res + (size_t)row[i] * N + c);
+                    const h4 r = rres[i][t];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
                 }
@@ -3331,13 +3343,24 @@ __global__ __launch_bounds__(512) void mid14m_kernel(Mid14Args a)
     {
         const _Float16* xg = a.X + (size_t)b * HW * Cin;
         constexpr int CPR = 4 * CKS;             // 16-byte chunks per staged row
-        for (int e = tid; e < HW * CPR; e += 512) {
-            const int row = e / CPR, cc = e - row * CPR;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (8 * cc < Cin) v = *reinterpret_cast<const uint4*>(xg + (size_t)row * Cin + 8 * cc);
-            *reinterpret_cast<uint4*>(XS + row * XSTR + 16 * cc) = v;
-        }
+        // all of a thread's chunks are requested before the first is stored (unconditional loads from clamped addresses: the loop used to
+        // be load -> vmcnt(0) -> store, six exposed round trips -- the 6 k cycles of "staging" in the first phase clock)
+        constexpr int NIT = (HW * CPR + 511) / 512;
+        uint4 xv[NIT];
         for (int e = lane; e < EREG / 16; e += 64) *reinterpret_cast<uint4*>(EW + 16 * e) = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e0 = tid + 512 * it, e = e0 < HW * CPR ? e0 : HW * CPR - 1;
+            const int row = e / CPR, cc = e - row * CPR;
+            xv[it] = *reinterpret_cast<const uint4*>(xg + (size_t)row * Cin + (8 * cc < Cin ? 8 * cc : Cin - 8));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 512 * it;
+            const int row = e / CPR, cc = e - row * CPR;
+            const uint4 v = 8 * cc < Cin ? xv[it] : uint4{0u, 0u, 0u, 0u};   // zero-padded k columns
+            if (e < HW * CPR) *reinterpret_cast<uint4*>(XS + row * XSTR + 16 * cc) = v;
+        }
     }
     __syncthreads();
     if (clk) ck[1] = (long long)__builtin_readcyclecounter();
