@@ -569,43 +569,49 @@ __global__ __launch_bounds__(256) void thin_proj_kernel(const _Float16* __restri
     // 8q .. 8q+7: the patch's gate values for those input channels): no gate registers (2 x 4 per k-step) and no per-fragment
     // scaling of the activations (8 conversions + products per k-step and fragment) -- what kept five-k-step layers (block 2's
     // project) slower here than on pw_gemm_kernel.  w * g rounded to fp16 instead of x * g: the same size of rounding error.
-    h8 wf[KSTEPS][2];
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        const int k = ks * 32 + q * 8;
-        f4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
-        if (k < K) {
-            g0 = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k);
-            g1 = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k + 4);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const uint4 w = *reinterpret_cast<const uint4*>(Wp + ((size_t)(ks * 2 + t) * 64 + lane) * 8);
-            const uint4 gw = gate_h8(w, g0, g1);
-            wf[ks][t] = *reinterpret_cast<const h8*>(&gw);
-        }
-    }
+    // Round 3: every request of the prologue goes out before anything is consumed -- the wave's first pixel fragment, then all gate
+    // values, then all weight fragments (it used to be gate -> wait -> weights -> wait per k-step, KSTEPS exposed round trips for a wave
+    // that streams three to seven fragments), all unconditional: columns past K re-read the last eight channels / gate values, finite
+    // numbers that meet zero weight rows (K is zero padded to whole k-steps in Wp).
     const int cbase = q * 8;   // lane (m,q) owns channels 8q .. 8q+7 (4t + j) of pixel row m of the fragment
-    const f4 bv0 = *reinterpret_cast<const f4*>(bias + cbase), bv1 = *reinterpret_cast<const f4*>(bias + cbase + 4);
+    const int cres = cbase < N ? cbase : 0;
     const _Float16* xb = X + (size_t)b * HW * K;
     auto load = [&](int f, h8 (&dst)[KSTEPS], h8& r) {
         const size_t row = (size_t)f * 16 + m;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int k = ks * 32 + q * 8;
-            h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (k < K) v = plane_rows ? *reinterpret_cast<const h8*>(X + (((size_t)ks * plane_rows + (size_t)b * HW + row) * 32 + q * 8))
-                                      : *reinterpret_cast<const h8*>(xb + row * K + k);
-            dst[ks] = v;
+            const int k0 = ks * 32 + q * 8, k = k0 < K ? k0 : K - 8;
+            dst[ks] = plane_rows ? *reinterpret_cast<const h8*>(X + (((size_t)(k >> 5) * plane_rows + (size_t)b * HW + row) * 32 + (k & 31)))
+                                 : *reinterpret_cast<const h8*>(xb + row * K + k);
         }
-        if (RES) {
-            r = (h8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (cbase < N) r = *reinterpret_cast<const h8*>(res + ((size_t)b * HW + row) * N + cbase);
-        }
+        if (RES) r = *reinterpret_cast<const h8*>(res + ((size_t)b * HW + row) * N + cres);
     };
     h8 xc[KSTEPS], xn[KSTEPS], rc = {0, 0, 0, 0, 0, 0, 0, 0}, rn = rc;
     int f = f0 + wave;
-    if (f < f1) load(f, xc, rc);
+    load(f < f1 ? f : f1 - 1, xc, rc);
+    h8 wf[KSTEPS][2];
+    {
+        f4 g0[KSTEPS], g1[KSTEPS];
+        uint4 wr[KSTEPS][2];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int k0 = ks * 32 + q * 8, k = k0 < K ? k0 : K - 8;
+            g0[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k);
+            g1[ks] = *reinterpret_cast<const f4*>(gate + (size_t)b * K + k + 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wr[ks][t] = *reinterpret_cast<const uint4*>(Wp + ((size_t)(ks * 2 + t) * 64 + lane) * 8);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 gw = gate_h8(wr[ks][t], g0[ks], g1[ks]);
+                wf[ks][t] = *reinterpret_cast<const h8*>(&gw);
+            }
+    }
+    const f4 bv0 = *reinterpret_cast<const f4*>(bias + cbase), bv1 = *reinterpret_cast<const f4*>(bias + cbase + 4);
     for (; f < f1; f += 4) {
         const bool more = f + 4 < f1;
         if (more) load(f + 4, xn, rn);
