@@ -161,6 +161,10 @@ def test_b4_fp8_project_convs_on_e4m3_operands(synth_sd_b4):
             assert not np.array_equal(got, half)          # the fp8 path really ran
         both = bb.extract(np.concatenate([ref.natural_patches(4, seed=7), ref.synthetic_patches(4, seed=42)]))
         assert np.array_equal(both, np.concatenate(outs))
+        # ragged row counts (1, 3 patches: 49 / 147 GEMM rows, partial 64-row workgroups) and an empty call
+        nat = ref.natural_patches(4, seed=7)
+        assert np.array_equal(bb.extract(nat[:1]), outs[0][:1]) and np.array_equal(bb.extract(nat[1:4]), outs[0][1:4])
+        assert bb.extract(nat[:0]).shape == (0, 1792)
     finally:
         bb.close()
         bh.close()
