@@ -68,6 +68,17 @@ static __device__ __forceinline__ float quad_sum(float v)
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
     return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), every lane getting the total: the quad sums, then row_half_mirror and
+// row_mirror.  After the quad stage a quad is uniform, so lane 7-i holds what lane i^4 holds (and, one stage later, lane 15-i what
+// lane i^8 holds): the additions are those of the xor butterfly v += shfl_xor(v, 1 | 2 | 4 | 8), bit for bit, without its four
+// dependent ds_bpermute round trips.
+static __device__ __forceinline__ float row16_sum(float v)
+{
+    v = quad_sum(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
 
 // The same on N accumulators at once, stage by stage (all exponentials, all adds, all reciprocals, all products): element by
 // element the four-instruction chain exp -> add -> rcp -> mul stalls on each transcendental's latency (the compiler pads it
@@ -369,11 +380,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const _Float16* __restrict
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = rok[0] ? silu_scaled(acc[0][t][j]) : 0.0f;
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
+                const float v = row16_sum(rok[0] ? silu_scaled(acc[0][t][j]) : 0.0f);
                 if (m == 0) red[wave * 16 * NT + q * 4 * NT + 4 * t + j] = v;
             }
         __syncthreads();
@@ -3038,12 +3045,7 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = sum[j];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    sum[j] = v * a.inv_hw;
+                    sum[j] = row16_sum(sum[j]) * a.inv_hw;
                 }
                 if (m == 0) *reinterpret_cast<f4*>(a.feat + (size_t)b * 1280 + 16 * (nfb + i) + 4 * q) = sum;
             }
