@@ -2726,16 +2726,20 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 uint32_t wp[2 * KS * NP];
                 tap_pairs(raw, wp);
                 unsigned char* col = ED + 2 * c;
+                // All 49 two-byte reads go out before the first pair is assembled: left alone the compiler reads two, waits
+                // (s_waitcnt lgkmcnt(0)), shifts and ors, 24 times over -- 24 LDS round trips in front of every round.
                 uint32_t P[28];
+                {
+                    uint16_t px[49];
 #pragma unroll
-                for (int y = 0; y < 7; ++y)
+                    for (int i = 0; i < 49; ++i) px[i] = *reinterpret_cast<const uint16_t*>(col + i * T7_ES);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {
-                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp) * T7_ES);
-                        uint32_t hi = 0;
-                        if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(col + (y * 7 + 2 * pp + 1) * T7_ES);
-                        P[y * 4 + pp] = lo | (hi << 16);
-                    }
+                    for (int y = 0; y < 7; ++y)
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp)
+                            P[y * 4 + pp] = (uint32_t)px[y * 7 + 2 * pp] | (pp < 3 ? (uint32_t)px[y * 7 + 2 * pp + 1] << 16 : 0u);
+                }
                 f2 psum2 = {0.f, 0.f};
                 float psum1 = 0.f;
 #pragma unroll
@@ -2805,17 +2809,25 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
                 tap_pairs(rawA, wpA);
                 unsigned char* col = ED + 2 * c;
                 uint32_t P[NR * 4];
+                {
+                    uint16_t px[NR * 7];   // (all reads first: see dw_round)
 #pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int iy = rb - R + r;
-                    const bool rok = iy >= 0 && iy < 7;
-                    const unsigned char* rowp = col + (rok ? iy : 0) * (7 * T7_ES);
+                    for (int r = 0; r < NR; ++r) {
+                        const int iy = rb - R + r;
+                        const unsigned char* rowp = col + ((iy >= 0 && iy < 7) ? iy : 0) * (7 * T7_ES);
 #pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {
-                        const uint32_t lo = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp) * T7_ES);
-                        uint32_t hi = 0;
-                        if (pp < 3) hi = *reinterpret_cast<const uint16_t*>(rowp + (2 * pp + 1) * T7_ES);
-                        P[r * 4 + pp] = rok ? (lo | (hi << 16)) : 0u;
+                        for (int x = 0; x < 7; ++x) px[r * 7 + x] = *reinterpret_cast<const uint16_t*>(rowp + x * T7_ES);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const int iy = rb - R + r;
+                        const bool rok = iy >= 0 && iy < 7;
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) {
+                            const uint32_t v = (uint32_t)px[r * 7 + 2 * pp] | (pp < 3 ? (uint32_t)px[r * 7 + 2 * pp + 1] << 16 : 0u);
+                            P[r * 4 + pp] = rok ? v : 0u;
+                        }
                     }
                 }
                 T7_BAR();
@@ -2873,11 +2885,23 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         // ---------------- squeeze-excite FC1: r = silu(br + pooled . Wr^T) ----------------
         // One patch per workgroup makes the two FCs matrix-VECTOR products: fp32 FMAs on fp16 weights (fixed
         // summation order).  The excite weights (48 x 8 bytes per thread) are requested before FC1 computes.
+        // (The second half of the excite weights goes out HERE, in front of FC1's arithmetic: behind it, the request had only the
+        // 48-thread partial reduction to arrive in, and FC2 started with s_waitcnt vmcnt(0).)
+#pragma unroll
+        for (int k = 12; k < 24; ++k) fw2[k] = gload<u4v>(W.we_t, (unsigned)((k * 288 + t2) * 16));
+        const f4 bev = gload<f4>(W.be, (unsigned)t2 * 16u);
+        PIN_VMEM();
         if (fc1_thr) {
+            // all 36 pool sums of this thread are requested before the first FMA (left alone the compiler reads two, waits, computes
+            // eight FMAs, eighteen times over: 18 LDS round trips = 2.5 k of this phase's 3.7 k cycles)
+            float xs[36];
+#pragma unroll
+            for (int i = 0; i < 18; ++i) { xs[2 * i] = pooled[64 * i + cr]; xs[2 * i + 1] = pooled[64 * i + 32 + cr]; }
+            __builtin_amdgcn_sched_barrier(0);
             f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
-                const float x0 = pooled[64 * i + cr], x1 = pooled[64 * i + 32 + cr];
+                const float x0 = xs[2 * i], x1 = xs[2 * i + 1];
                 acc[0] = fma_mix_lo(fw1[i].x, x0, acc[0]);
                 acc[1] = fma_mix_hi(fw1[i].x, x0, acc[1]);
                 acc[2] = fma_mix_lo(fw1[i].y, x0, acc[2]);
@@ -2889,11 +2913,6 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
             }
             *reinterpret_cast<f4*>(part + cr * 48 + 4 * j4) = acc;
         }
-        PIN_VMEM();
-#pragma unroll
-        for (int k = 12; k < 24; ++k) fw2[k] = gload<u4v>(W.we_t, (unsigned)((k * 288 + t2) * 16));
-        const f4 bev = gload<f4>(W.be, (unsigned)t2 * 16u);
-        PIN_VMEM();
         T7_BAR();
         if (tid < 48) {
             float pv[32];   // all 32 partials requested at once (one LDS latency, not 32), summed in the fixed order
@@ -2909,10 +2928,14 @@ __global__ __launch_bounds__(512) void tail7_kernel(TailArgs a)
         T7_TICK();
         // ---------------- FC2: gate = sigmoid(be + r . We^T) ----------------
         if (fc2_thr) {
+            f4 rq[12];   // the 48 squeeze outputs (broadcast reads), all requested before the first FMA
+#pragma unroll
+            for (int k = 0; k < 12; ++k) rq[k] = *reinterpret_cast<const f4*>(rs + 4 * k);
+            __builtin_amdgcn_sched_barrier(0);
             f4 acc = bev;
 #pragma unroll
             for (int k = 0; k < 24; ++k) {
-                const float r0 = rs[2 * k], r1 = rs[2 * k + 1];
+                const float r0 = rq[k >> 1][2 * (k & 1)], r1 = rq[k >> 1][2 * (k & 1) + 1];
                 acc[0] = fma_mix_lo(fw2[k].x, r0, acc[0]);
                 acc[1] = fma_mix_hi(fw2[k].x, r0, acc[1]);
                 acc[2] = fma_mix_lo(fw2[k].y, r0, acc[2]);
