@@ -1083,12 +1083,25 @@ __global__ __launch_bounds__(1024) void se_wide_kernel(const float* __restrict__
             float w[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) w[u] = wr[(size_t)j * C + (c0 + 64 * u < C ? c0 + 64 * u : C - 1)];
+            // (the pool sums of eight channels x PB patches per LDS round trip: read inside the FMA loop they were one exposed round
+            // trip per FMA)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int c = c0 + 64 * u;
-                const int cl = c < C ? c : C - 1;
+            for (int h = 0; h < 2; ++h) {
+                float x[8][PB];
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) s[pb] = c < C ? __builtin_fmaf(pooled[pb * C + cl], w[u], s[pb]) : s[pb];
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + 64 * (8 * h + u);
+                    const int cl = c < C ? c : C - 1;
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) x[u][pb] = pooled[pb * C + cl];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + 64 * (8 * h + u);
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) s[pb] = c < C ? __builtin_fmaf(x[u][pb], w[8 * h + u], s[pb]) : s[pb];
+                }
             }
         }
 #pragma unroll
@@ -1119,14 +1132,22 @@ __global__ __launch_bounds__(1024) void se_wide_kernel(const float* __restrict__
                 for (int u = 0; u < 16; ++u) w[k][u] = we[(size_t)(j0 + u < Cs ? j0 + u : Cs - 1) * C + c];
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int j = j0 + u < Cs ? j0 + u : Cs - 1;
+            for (int h = 0; h < 2; ++h) {
+                float r[8][PB];   // (eight squeeze units x PB patches per LDS round trip)
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    const float r = rs[pb * Cs + j];
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + 8 * h + u < Cs ? j0 + 8 * h + u : Cs - 1;
 #pragma unroll
-                    for (int k = 0; k < NC; ++k) acc[k][pb] = j0 + u < Cs ? __builtin_fmaf(r, w[k][u], acc[k][pb]) : acc[k][pb];
+                    for (int pb = 0; pb < PB; ++pb) r[u][pb] = rs[pb * Cs + j];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                        for (int k = 0; k < NC; ++k)
+                            acc[k][pb] = j0 + 8 * h + u < Cs ? __builtin_fmaf(r[u][pb], w[k][8 * h + u], acc[k][pb]) : acc[k][pb];
             }
         }
 #pragma unroll
@@ -1437,6 +1458,9 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks)
                     wc[ks] = *reinterpret_cast<const h8*>(wfr + ((t * KSTEPS + ks) * 64 + lane) * 8);
+                // all KSTEPS fragments in one LDS round trip: left alone the compiler sinks each read next to its two MFMAs behind an
+                // s_waitcnt lgkmcnt(0) (B4's 7x7 stage: fourteen exposed round trips per 16 output channels)
+                __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
                 for (int ks = 0; ks < KSTEPS; ++ks) wc[ks] = wn[ks];
@@ -4140,22 +4164,35 @@ __global__ __launch_bounds__(512, 4) void mbt4_kernel(MbtArgs a)
             const f4 bdv = {bd, bd, bd, bd};
             f4 acc[4];
             const unsigned char* rb = dld + 16 * g * ECS;
+            // Quads two kernel rows ahead of their MFMAs (rows 0, 1 before the first MFMA, row ky + 2 into the slot row ky has just freed),
+            // pinned: left alone the compiler sinks every read next to its MFMAs -- a read, s_waitcnt lgkmcnt(1), three MFMAs, twenty times
+            // per item.  (All five rows up front: 13 registers spilled at the 128 this kernel may use; three ahead: 3.)
+            h4 ql[2][4];
+            auto quads = [&](int ky) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ql[ky & 1][k] = *reinterpret_cast<const h4*>(rb + ky * ERS + 8 * k);
+            };
+            quads(0); quads(1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ky = 0; ky < KSD; ++ky) {
-                h4 ql[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ql[k] = *reinterpret_cast<const h4*>(rb + ky * ERS + 8 * k);
                 const h4 a0 = __builtin_bit_cast(h4, ta[ky][0]), a1 = __builtin_bit_cast(h4, ta[ky][1]);
+                const h4 (&qk)[4] = ql[ky & 1];
                 if (XH == 0) {   // tiles at columns -2, 2, 6, 10: quad t with the h = 1 slice, quad t - 1 with the h = 0 slice (tile 0's left quad is the zero border)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, ql[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, qk[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, ql[t - 1], acc[t], 0, 0, 0);
+                    for (int t = 1; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, qk[t - 1], acc[t], 0, 0, 0);
                 } else {         // tiles at columns 14, 18, 22, 26: local quad t (= quad 3 + t) with h = 0, local quad t + 1 with h = 1 (tile 3's right quad is the zero border)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, ql[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, qk[t], ky == 0 ? bdv : acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, ql[t + 1], acc[t], 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, qk[t + 1], acc[t], 0, 0, 0);
+                }
+                if (ky + 2 < KSD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    quads(ky + 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             float v[14];
@@ -4426,57 +4463,6 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.wr_t);
     const GLOBAL_AS _Float16* we_t = sgpr_ptr<_Float16>(a.we_t);
     const GLOBAL_AS float* pp = sgpr_ptr<float>(a.pool_part);
-    // ---- The prologue is a dependent chain (pool sums -> FC1 -> FC2 -> gate) beside ~300 KB of bulk loads (project
-    //      weights, first pixel fragments).  Loads return in order and a wave cannot pass a barrier before it has
-    //      ISSUED its loads (the memory pipe takes 64 B/clk), so: chain inputs first (pool partials, then the FC
-    //      weights), all unpredicated and straight-line; the bulk loads go out after the first barrier and stream
-    //      in while the FCs compute.
-    // Pool channels: thread t takes channel t and channel t + 512 -- except wave 7 (it issues the weight DMA below and would get its
-    // sums back only behind it): its channels 448 .. 511 ride in the second slot of threads 160 .. 223, which is free (K <= 672).
-    static_assert(KP <= 672, "channel 448..511 reassignment assumes no channel t + 512 for t >= 160");
-    float ps0 = 0.f, ps1 = 0.f;
-    const int pk0 = tid, pk1 = (tid >= 160 && tid < 224) ? tid + 288 : tid + 512;
-    const bool pw = wave != 7;
-    {
-        const int k0 = (pw && pk0 < K) ? pk0 : 0, k1 = (pw && pk1 < K) ? pk1 : 0;
-        if (a.nparts == 1) {
-            ps0 = gload<float>(pp, (unsigned)((b * K + k0) * 4));
-            ps1 = gload<float>(pp, (unsigned)((b * K + k1) * 4));
-        } else {   // up to 16 tiles per patch (b3: 14, b4: 4, b5: 7): every load issued before the first add
-            float v0[16], v1[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int pc = p < a.nparts ? p : 0;
-                v0[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k0) * 4));
-                v1[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k1) * 4));
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                ps0 += p < a.nparts ? v0[p] : 0.f;
-                ps1 += p < a.nparts ? v1[p] : 0.f;
-            }
-        }
-    }
-    // FC1: thread = 4 outputs (j4) x one of 64 channel slices (k = sl, sl + 64, ...)
-    constexpr int FC1_IT = (KP + 63) / 64;
-    const int G = CSP >> 2;
-    const int sl = tid / G, j4 = tid - sl * G;
-    const bool fc1_thr = sl < 64;
-    u2v w1[FC1_IT];
-#pragma unroll
-    for (int i = 0; i < FC1_IT; ++i) {
-        const int k = sl + 64 * i;
-        w1[i] = gload<u2v>(wr_t, (unsigned)(((fc1_thr && k < K ? k : 0) * CSP + 4 * j4) * 2));
-    }
-    // FC2: thread = channels 2*tid, 2*tid + 1 (one dword of We^T per squeeze unit)
-    const int k2 = 2 * tid;
-    const bool fc2_thr = k2 < K;
-    uint32_t w2[28];
-#pragma unroll
-    for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
-    const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
-    const int rt = tid - 448;   // the reduce runs in wave 7 (threads 448 .. 448 + CSP - 1)
-    const float brv = (rt >= 0 && rt < CSP) ? a.br[rt] : 0.f;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
     auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
 #pragma unroll
@@ -4506,18 +4492,94 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     // workgroup in front of the chain -- the pooled barrier came at 15 k cycles.  They go out behind FC1, in the waves that idle there.)
     // A CU's memory pipe serves requests in issue order, whichever wave they come from: the barrier puts every wave's chain inputs in
     // the queue ahead of the first DMA piece (without it the pool sums came back behind the weights: pooled barrier at 11 k cycles).
-    h8 xc[2][CK], xn[2][CK];
-    PIN_VMEM();
-    __builtin_amdgcn_s_barrier();
-    if (wave == 7) {
-#pragma unroll 7
-        for (int i = 0; i < NF * KS; ++i)
+    // The DMA goes out in four slices, one in front of each barrier of the chain: a wave's memory queue holds ~64 requests and takes
+    // ~40 cycles per 1-KB piece, so wave 7 issuing all of them (up to 147) in front of the pooled barrier held every other wave there
+    // for up to 6 k cycles (phase clock: pooled barrier at 10-11 k cycles for K = 672, 5 k for K = 144).  Slice sizes are what the
+    // other waves' work between two barriers covers; wave 7 does nothing else in the prologue (the reduce moved to wave 0).
+    constexpr int NW = NF * KS;
+    constexpr int DS0 = NW < 40 ? NW : 40, DS1 = NW - DS0 < 36 ? NW - DS0 : 36, DS2 = NW - DS0 - DS1 < 40 ? NW - DS0 - DS1 : 40;
+    // (Every workgroup fetches the same image in the same order at about the same time; starting each at a different sixteenth of it
+    // -- so that the workgroups of an XCD do not ask one L2 channel for the same line together -- changed nothing: measured.  Larger
+    // first slices (72 / 25 / 35) moved the pooled barrier out by what they took.)
+    auto dma = [&](auto i0_tag, auto i1_tag) {
+        constexpr int I0 = decltype(i0_tag)::value, I1 = decltype(i1_tag)::value;
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wfrag + ((size_t)i * 64 + lane) * 8),
                                              (__attribute__((address_space(3))) void*)(wl + i * 1024), 16, 0, 0);
         PIN_VMEM();
-    }
-    if (pw && pk0 < KP) pooled[pk0] = pk0 < K ? ps0 : 0.f;
-    if (pw && pk1 < KP) pooled[pk1] = pk1 < K ? ps1 : 0.f;
+    };
+    h8 xc[2][CK], xn[2][CK];
+    // Wave 7 runs its own straight-line path with the chain's four barriers in it: hipcc cannot count vmcnt across a DMA (LDS-DMA
+    // pieces retire out of order with plain loads), so in a shared path every wave would meet s_waitcnt vmcnt(0) at each use of a
+    // loaded register behind a point where a DMA MAY be in flight -- FC2 would wait for the first pixel fragments, and so on.
+    if (wave == 7) {
+        __builtin_amdgcn_s_barrier();   // (the other waves' chain inputs are in the memory queue)
+        dma(std::integral_constant<int, 0>{}, std::integral_constant<int, DS0>{});
+        T7_BAR();   // pooled
+        dma(std::integral_constant<int, DS0>{}, std::integral_constant<int, DS0 + DS1>{});
+        T7_BAR();   // FC1
+        dma(std::integral_constant<int, DS0 + DS1>{}, std::integral_constant<int, DS0 + DS1 + DS2>{});
+        T7_BAR();   // reduce
+        dma(std::integral_constant<int, DS0 + DS1 + DS2>{}, std::integral_constant<int, NW>{});
+        if (7 < NPAIR) { load_chunk(7, 0, xc); PIN_VMEM(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed
+        T7_BAR();   // FC2 / gate
+    } else {
+        // ---- The prologue is a dependent chain (pool sums -> FC1 -> FC2 -> gate) beside ~300 KB of bulk loads (project
+        //      weights, first pixel fragments).  Loads return in order and a wave cannot pass a barrier before it has
+        //      ISSUED its loads (the memory pipe takes 64 B/clk), so: chain inputs first (pool partials, then the FC
+        //      weights), all unpredicated and straight-line; the bulk loads go out after the first barrier and stream
+        //      in while the FCs compute.
+        // Pool channels: thread t takes channel t and channel t + 512 -- except wave 7 (the DMA path above): its channels 448 .. 511
+        // ride in the second slot of threads 160 .. 223, which is free (K <= 672).
+        static_assert(KP <= 672, "channel 448..511 reassignment assumes no channel t + 512 for t >= 160");
+        float ps0 = 0.f, ps1 = 0.f;
+        const int pk0 = tid, pk1 = (tid >= 160 && tid < 224) ? tid + 288 : tid + 512;
+        {
+            const int k0 = pk0 < K ? pk0 : 0, k1 = pk1 < K ? pk1 : 0;
+            if (a.nparts == 1) {
+                ps0 = gload<float>(pp, (unsigned)((b * K + k0) * 4));
+                ps1 = gload<float>(pp, (unsigned)((b * K + k1) * 4));
+            } else {   // up to 16 tiles per patch (b3: 14, b4: 4, b5: 7): every load issued before the first add
+                float v0[16], v1[16];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const int pc = p < a.nparts ? p : 0;
+                    v0[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k0) * 4));
+                    v1[p] = gload<float>(pp, (unsigned)(((b * a.nparts + pc) * K + k1) * 4));
+                }
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    ps0 += p < a.nparts ? v0[p] : 0.f;
+                    ps1 += p < a.nparts ? v1[p] : 0.f;
+                }
+            }
+        }
+        // FC1: thread = 4 outputs (j4) x one of 64 channel slices (k = sl, sl + 64, ...)
+        constexpr int FC1_IT = (KP + 63) / 64;
+        const int G = CSP >> 2;
+        const int sl = tid / G, j4 = tid - sl * G;
+        const bool fc1_thr = sl < 64;
+        u2v w1[FC1_IT];
+#pragma unroll
+        for (int i = 0; i < FC1_IT; ++i) {
+            const int k = sl + 64 * i;
+            w1[i] = gload<u2v>(wr_t, (unsigned)(((fc1_thr && k < K ? k : 0) * CSP + 4 * j4) * 2));
+        }
+        // FC2: thread = channels 2*tid, 2*tid + 1 (one dword of We^T per squeeze unit)
+        const int k2 = 2 * tid;
+        const bool fc2_thr = k2 < K;
+        uint32_t w2[28];
+#pragma unroll
+        for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
+        const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
+        const int rt = tid;         // the reduce runs in wave 0 (threads 0 .. CSP - 1)
+        const float brv = rt < CSP ? a.br[rt] : 0.f;
+    PIN_VMEM();
+    __builtin_amdgcn_s_barrier();
+    if (pk0 < KP) pooled[pk0] = pk0 < K ? ps0 : 0.f;
+    if (pk1 < KP) pooled[pk1] = pk1 < K ? ps1 : 0.f;
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 3] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC1: r = silu(br + psc * pooled . Wr^T) ----
@@ -4525,11 +4587,20 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     // HERE, in front of FC1: their address processing alone takes ~4 k cycles per workgroup and FC1's barrier came 9-10 k cycles
     // after the pooled one.  They are needed only after FC2, so they now go out behind FC1 and stream in under the reduce and FC2.)
     if (fc1_thr) {
+        // the thread's pool sums in ONE LDS round trip (clamped addresses, no branch around a read): read one by one behind
+        // `k < K ?` they were up to eleven dependent round trips in a prologue no other wave can fill
+        float xs[FC1_IT];
+#pragma unroll
+        for (int i = 0; i < FC1_IT; ++i) {
+            const int k = sl + 64 * i;
+            xs[i] = pooled[k < K ? k : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < FC1_IT; ++i) {
             const int k = sl + 64 * i;
-            const float x = k < K ? pooled[k] : 0.f;
+            const float x = k < K ? xs[i] : 0.f;
             acc[0] = fma_mix_lo(w1[i].x, x, acc[0]);
             acc[1] = fma_mix_hi(w1[i].x, x, acc[1]);
             acc[2] = fma_mix_lo(w1[i].y, x, acc[2]);
@@ -4539,10 +4610,13 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     }
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
-    // first pixel fragments of every wave (wave 7's behind its reduce)
-    if (wave != 7 && wave < NPAIR) { load_chunk(wave, 0, xc); PIN_VMEM(); }
-    // wave 7 (idle during FC1) reduces FC1's partials
-    if (wave == 7 && rt < CSP) {
+    // first pixel fragments of every wave (wave 7's behind the last DMA slice), unconditional: every layer has at least seven
+    // pairs of pixel fragments, and a load behind a branch would cost the chain its counted waits
+    static_assert(NPAIR >= 7, "waves 0..6 all own a pair of pixel fragments");
+    load_chunk(wave, 0, xc);
+    PIN_VMEM();
+    // wave 0 reduces FC1's partials
+    if (wave == 0 && rt < CSP) {
         float s = 0.f;   // 16 partials per round of LDS reads (one latency per 16, not per partial), summed in the fixed order
 #pragma unroll
         for (int w0 = 0; w0 < 64; w0 += 16) {
@@ -4554,19 +4628,22 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         }
         rs[rt] = silu_f(s * a.psc + brv);
     }
-    if (wave == 7 && wave < NPAIR) { load_chunk(wave, 0, xc); PIN_VMEM(); }
     T7_BAR();
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 5] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC2: gate = sigmoid(be + r . We^T) ----
-    {
+    if (k2 < KP) {   // (whole waves beyond K skip it: wave 7 must not wait here for operands queued behind its DMA)
         float a0 = be0, a1 = be1;
+        f4 rq[7];   // all 28 squeeze slots in one round trip (slots >= CSP hold whatever: selected to zero below)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) rq[j] = *reinterpret_cast<const f4*>(rs + 4 * j);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 28; ++j) {
-            const float r = j < CSP ? rs[j] : 0.f;
+            const float r = j < CSP ? rq[j >> 2][j & 3] : 0.f;
             a0 = fma_mix_lo(w2[j], r, a0);
             a1 = fma_mix_hi(w2[j], r, a1);
         }
-        if (k2 < KP) {   // zero beyond K: the zero-padded x columns stay zero
+        {   // zero beyond K: the zero-padded x columns stay zero
             const float g0 = fc2_thr ? sigmoid_f(a0) : 0.f, g1 = fc2_thr ? sigmoid_f(a1) : 0.f;
             gate[k2] = g0;
             gate[k2 + 1] = g1;
@@ -4577,8 +4654,8 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         }
     }
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 6] = (float)((long long)__builtin_readcyclecounter() - tk0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // wave 7: the DMA has landed
     T7_BAR();
+    }
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 7] = (float)((long long)__builtin_readcyclecounter() - tk0);
     if (a.dbg_clk) tk1 = (long long)__builtin_readcyclecounter();
     // ---- project: Y[pixel][n] = sum_k (X[pixel][k] * gate[k]) W[n][k] + bias (+ residual) ----
