@@ -180,7 +180,7 @@ int launch_mid14(const Mid14Args& a, hipStream_t st);
 struct ProjPatchArgs {
     const _Float16* X;        // [B][HW][K] depthwise output
     const float* pool_part;   // [B][nparts][K] depthwise pool partials
-    const _Float16* wr_t;     // [K][CSP] squeeze FC (fp16, channel-major)
+    const _Float16* wr_g;     // [CSP/4][proj_patch_fc1_rows(K)][4] squeeze FC (fp16; group of four outputs, channel, output; zero beyond K)
     const float* br;          // [CSP]
     const _Float16* we_t;     // [CSP][K] excite FC (fp16)
     const float* be;          // [K]
@@ -195,6 +195,7 @@ struct ProjPatchArgs {
 };
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st);
 int proj_patch_ksteps(int K);                        // k-steps (of 32) its weight image must be packed with
+int proj_patch_fc1_rows(int K);                      // channel rows per output group of ProjPatchArgs::wr_g (64 x the kernel's FC1 iterations)
 int proj_patch_has(int K, int N, int HW, int res);   // 1 when launch_proj_patch has an instantiation for this layer shape
 
 int launch_mbconv_a(const MbArgs& a, hipStream_t st);

@@ -4450,9 +4450,6 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     float* pooled = reinterpret_cast<float*>(smem + NF * KS * 1024);    // [KP]
     float* gate = pooled + KP;                                          // [KP]
     float* rs = gate + KP;                                              // [32] squeeze activations
-    float* part = rs + 32;                                              // [64][28] FC1 partials (outside wl: the weights stream into
-                                                                        // LDS by DMA while the reduce reads them)
-    constexpr int PST = 28;                                             // row stride of part (CSP <= 28)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
@@ -4460,9 +4457,12 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     long long tk0 = 0, tk1 = 0, tk2 = 0;
     if (a.dbg_clk) tk0 = (long long)__builtin_readcyclecounter();
     const GLOBAL_AS _Float16* wfrag = sgpr_ptr<_Float16>(a.wfrag);
-    const GLOBAL_AS _Float16* wr_t = sgpr_ptr<_Float16>(a.wr_t);
+    const GLOBAL_AS _Float16* wr_g = sgpr_ptr<_Float16>(a.wr_g);
     const GLOBAL_AS _Float16* we_t = sgpr_ptr<_Float16>(a.we_t);
     const GLOBAL_AS float* pp = sgpr_ptr<float>(a.pool_part);
+    constexpr int FC1_IT = (KP + 63) / 64, KPAD = 64 * FC1_IT;   // FC1: channel slices of 64 per lane (see below)
+    const int G = CSP >> 2;
+    const bool fc1_wave = wave < G;
     const GLOBAL_AS _Float16* xg = sgpr_ptr<_Float16>(a.X) + (size_t)b * HW * K;
     auto load_chunk = [&](int pr, int ch, h8 (&dst)[2][CK]) {
 #pragma unroll
@@ -4492,12 +4492,12 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     // workgroup in front of the chain -- the pooled barrier came at 15 k cycles.  They go out behind FC1, in the waves that idle there.)
     // A CU's memory pipe serves requests in issue order, whichever wave they come from: the barrier puts every wave's chain inputs in
     // the queue ahead of the first DMA piece (without it the pool sums came back behind the weights: pooled barrier at 11 k cycles).
-    // The DMA goes out in four slices, one in front of each barrier of the chain: a wave's memory queue holds ~64 requests and takes
+    // The DMA goes out in three slices, one in front of each barrier of the chain: a wave's memory queue holds ~64 requests and takes
     // ~40 cycles per 1-KB piece, so wave 7 issuing all of them (up to 147) in front of the pooled barrier held every other wave there
     // for up to 6 k cycles (phase clock: pooled barrier at 10-11 k cycles for K = 672, 5 k for K = 144).  Slice sizes are what the
     // other waves' work between two barriers covers; wave 7 does nothing else in the prologue (the reduce moved to wave 0).
     constexpr int NW = NF * KS;
-    constexpr int DS0 = NW < 40 ? NW : 40, DS1 = NW - DS0 < 36 ? NW - DS0 : 36, DS2 = NW - DS0 - DS1 < 40 ? NW - DS0 - DS1 : 40;
+    constexpr int DS0 = NW < 44 ? NW : 44, DS1 = NW - DS0 < 50 ? NW - DS0 : 50;
     // (Every workgroup fetches the same image in the same order at about the same time; starting each at a different sixteenth of it
     // -- so that the workgroups of an XCD do not ask one L2 channel for the same line together -- changed nothing: measured.  Larger
     // first slices (72 / 25 / 35) moved the pooled barrier out by what they took.)
@@ -4519,9 +4519,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         T7_BAR();   // pooled
         dma(std::integral_constant<int, DS0>{}, std::integral_constant<int, DS0 + DS1>{});
         T7_BAR();   // FC1
-        dma(std::integral_constant<int, DS0 + DS1>{}, std::integral_constant<int, DS0 + DS1 + DS2>{});
-        T7_BAR();   // reduce
-        dma(std::integral_constant<int, DS0 + DS1 + DS2>{}, std::integral_constant<int, NW>{});
+        dma(std::integral_constant<int, DS0 + DS1>{}, std::integral_constant<int, NW>{});
         if (7 < NPAIR) { load_chunk(7, 0, xc); PIN_VMEM(); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed
         T7_BAR();   // FC2 / gate
@@ -4556,17 +4554,14 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
                 }
             }
         }
-        // FC1: thread = 4 outputs (j4) x one of 64 channel slices (k = sl, sl + 64, ...)
-        constexpr int FC1_IT = (KP + 63) / 64;
-        const int G = CSP >> 2;
-        const int sl = tid / G, j4 = tid - sl * G;
-        const bool fc1_thr = sl < 64;
+        // FC1: wave = 4 outputs (group j4 = wave < CSP / 4), lane = one of 64 channel slices (k = lane, lane + 64, ...): the 64 partial
+        // sums of an output are the lanes of ONE wave and add up on DPP row operations + four v_readlane -- no partials in LDS, no
+        // reduce stage, one barrier less in the chain (that stage took 2.1-3.0 k of the prologue's 10-14.7 k cycles).  Weights
+        // host-packed [group][64 * FC1_IT channels][4] (zero beyond K): a lane's request is 8 bytes next to its neighbours'.
+        const int wj = fc1_wave ? wave : 0;   // (idle waves re-read group 0: no branch around the loads)
         u2v w1[FC1_IT];
 #pragma unroll
-        for (int i = 0; i < FC1_IT; ++i) {
-            const int k = sl + 64 * i;
-            w1[i] = gload<u2v>(wr_t, (unsigned)(((fc1_thr && k < K ? k : 0) * CSP + 4 * j4) * 2));
-        }
+        for (int i = 0; i < FC1_IT; ++i) w1[i] = gload<u2v>(wr_g, (unsigned)(((wj * KPAD + lane + 64 * i) * 4) * 2));
         // FC2: thread = channels 2*tid, 2*tid + 1 (one dword of We^T per squeeze unit)
         const int k2 = 2 * tid;
         const bool fc2_thr = k2 < K;
@@ -4574,8 +4569,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 #pragma unroll
         for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
         const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
-        const int rt = tid;         // the reduce runs in wave 0 (threads 0 .. CSP - 1)
-        const float brv = rt < CSP ? a.br[rt] : 0.f;
+        const float brv = a.br[4 * wj + (lane & 3)];   // squeeze bias of output 4 * wave + lane (lanes 0 .. 3 finish FC1; br is padded to 32)
     PIN_VMEM();
     __builtin_amdgcn_s_barrier();
     if (pk0 < KP) pooled[pk0] = pk0 < K ? ps0 : 0.f;
@@ -4586,50 +4580,47 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     // (The bulk loads -- 147 KB of project weights and the first pixel fragments, 33 x 16 bytes per thread -- used to be issued
     // HERE, in front of FC1: their address processing alone takes ~4 k cycles per workgroup and FC1's barrier came 9-10 k cycles
     // after the pooled one.  They are needed only after FC2, so they now go out behind FC1 and stream in under the reduce and FC2.)
-    if (fc1_thr) {
-        // the thread's pool sums in ONE LDS round trip (clamped addresses, no branch around a read): read one by one behind
-        // `k < K ?` they were up to eleven dependent round trips in a prologue no other wave can fill
+    if (fc1_wave) {
+        // the lane's pool sums in ONE LDS round trip (clamped addresses: slots beyond the padded K meet zero weights)
         float xs[FC1_IT];
 #pragma unroll
         for (int i = 0; i < FC1_IT; ++i) {
-            const int k = sl + 64 * i;
-            xs[i] = pooled[k < K ? k : 0];
+            const int k = lane + 64 * i;
+            xs[i] = pooled[k < KP ? k : 0];
         }
         __builtin_amdgcn_sched_barrier(0);
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < FC1_IT; ++i) {
-            const int k = sl + 64 * i;
-            const float x = k < K ? xs[i] : 0.f;
-            acc[0] = fma_mix_lo(w1[i].x, x, acc[0]);
-            acc[1] = fma_mix_hi(w1[i].x, x, acc[1]);
-            acc[2] = fma_mix_lo(w1[i].y, x, acc[2]);
-            acc[3] = fma_mix_hi(w1[i].y, x, acc[3]);
+            acc[0] = fma_mix_lo(w1[i].x, xs[i], acc[0]);
+            acc[1] = fma_mix_hi(w1[i].x, xs[i], acc[1]);
+            acc[2] = fma_mix_lo(w1[i].y, xs[i], acc[2]);
+            acc[3] = fma_mix_hi(w1[i].y, xs[i], acc[3]);
         }
-        *reinterpret_cast<f4*>(part + sl * PST + 4 * j4) = acc;
+        float tot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // fixed order: rows of 16 lanes on DPP, then (row 0 + row 1) + (row 2 + row 3)
+            const int v = __builtin_bit_cast(int, row16_sum(acc[j]));
+            tot[j] = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 16))) +
+                     (__builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, 48)));
+        }
+        if (lane < 4) {
+            const float sv = lane == 0 ? tot[0] : (lane == 1 ? tot[1] : (lane == 2 ? tot[2] : tot[3]));
+            rs[4 * wave + lane] = silu_f(sv * a.psc + brv);
+        }
     }
     T7_BAR();
-    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
+    if (a.dbg_clk && tid == 0) {
+        a.dbg_clk[(size_t)b * 8 + 4] = (float)((long long)__builtin_readcyclecounter() - tk0);
+        a.dbg_clk[(size_t)b * 8 + 5] = a.dbg_clk[(size_t)b * 8 + 4];   // (the reduce stage is gone: same stamp)
+    }
     // first pixel fragments of every wave (wave 7's behind the last DMA slice), unconditional: every layer has at least seven
-    // pairs of pixel fragments, and a load behind a branch would cost the chain its counted waits
+    // pairs of pixel fragments, and a load behind a branch would cost the chain its counted waits.  Behind FC1's barrier (a wave
+    // passes a barrier only once its loads are ISSUED -- in front of it, block 4's 112 KB held the barrier for 4 k cycles); FC2
+    // waits with a counted vmcnt for its own operands only.
     static_assert(NPAIR >= 7, "waves 0..6 all own a pair of pixel fragments");
     load_chunk(wave, 0, xc);
     PIN_VMEM();
-    // wave 0 reduces FC1's partials
-    if (wave == 0 && rt < CSP) {
-        float s = 0.f;   // 16 partials per round of LDS reads (one latency per 16, not per partial), summed in the fixed order
-#pragma unroll
-        for (int w0 = 0; w0 < 64; w0 += 16) {
-            float pv[16];
-#pragma unroll
-            for (int w = 0; w < 16; ++w) pv[w] = part[(w0 + w) * PST + rt];
-#pragma unroll
-            for (int w = 0; w < 16; ++w) s += pv[w];
-        }
-        rs[rt] = silu_f(s * a.psc + brv);
-    }
-    T7_BAR();
-    if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 5] = (float)((long long)__builtin_readcyclecounter() - tk0);
     // ---- FC2: gate = sigmoid(be + r . We^T) ----
     if (k2 < KP) {   // (whole waves beyond K skip it: wave 7 must not wait here for operands queued behind its DMA)
         float a0 = be0, a1 = be1;
@@ -5414,10 +5405,12 @@ int proj_patch_ksteps(int K)
     return ks == 11 ? 12 : ks;
 }
 
+int proj_patch_fc1_rows(int K) { return 64 * ((32 * proj_patch_ksteps(K) + 63) / 64); }
+
 template <int KS, int NF, int HW, bool RES>
 static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 {
-    const int lds = NF * KS * 1024 + 2 * 32 * KS * 4 + 128 + 64 * 28 * 4;   // project weights, pooled + gate vectors, squeeze activations, FC1 partials
+    const int lds = NF * KS * 1024 + 2 * 32 * KS * 4 + 128;   // project weights, pooled + gate vectors, squeeze activations
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_patch_kernel<KS, NF, HW, RES>),
@@ -5432,7 +5425,7 @@ static int launch_proj_patch_t(const ProjPatchArgs& a, hipStream_t st)
 
 int launch_proj_patch(const ProjPatchArgs& a, hipStream_t st)
 {
-    // CSP <= 28: FC1's partial rows have stride PST = 28 and wave 7 (threads 448..) must have no part in FC1 (G = CSP / 4 <= 7)
+    // CSP <= 28: FC1's output groups are waves 0 .. CSP / 4 - 1 and wave 7 (the DMA path) must not be one of them
     if (a.B < 1 || a.CSP < 4 || a.CSP > 28 || (a.CSP & 3) || a.nparts < 1) return -11;
     const int ks = proj_patch_ksteps(a.K), nf = (a.N + 15) / 16;
 #define PP_CASE(KS_, NF_, HW_, RES_) \

@@ -205,6 +205,7 @@ struct BlockW {
     uint32_t* t_dwp4 = nullptr;  // taps + bias, [4][ce][4] dwords (16-byte requests)
     _Float16* dw_diag = nullptr;  // mid14m_kernel: Toeplitz depthwise fragments [ce/16][k][2][64][4] for v_mfma_f32_4x4x4_16B_f16 (depthwise on the matrix pipe)
     _Float16 *t_wr = nullptr, *t_we = nullptr;   // squeeze-excite FCs transposed (fp16) for matrix-vector use
+    _Float16* t_wrg = nullptr;                   // ... the squeeze FC as proj_patch_kernel reads it (ProjPatchArgs::wr_g)
     _Float16 *t_wr2 = nullptr, *t_we2 = nullptr; // ... blocks 12-15: paired rows for tail7_kernel's 16-byte requests
     // proj_patch_kernel packing (blocks 3..10): project weights/bias padded to whole fragments, SE FCs as above with
     // Cs padded to a multiple of 4
@@ -702,6 +703,15 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
                     }
                 TRY_OR_FREE(dev_upload(bb, &B.t_wr, wrt));
                 TRY_OR_FREE(dev_upload(bb, &B.t_we, wet));
+                if (pp_blk && csp <= 28) {
+                    // proj_patch_kernel's FC1: [group of four outputs][channel row][4] (ProjPatchArgs::wr_g), zero beyond ce
+                    const int rows = proj_patch_fc1_rows(B.ce);
+                    std::vector<_Float16> wrg((size_t)(csp / 4) * rows * 4, (_Float16)0.0f);
+                    for (int g = 0; g < csp / 4; ++g)
+                        for (int c = 0; c < B.ce; ++c)
+                            for (int e = 0; e < 4; ++e) wrg[((size_t)g * rows + c) * 4 + e] = wrt[(size_t)c * csp + 4 * g + e];
+                    TRY_OR_FREE(dev_upload(bb, &B.t_wrg, wrg));
+                }
                 if (tail_enabled && i >= 12 && i <= 15 && B.cs == 48 && B.ce == 1152) {
                     // tail7_kernel's 16-byte request layout (TailBlock::wr_t / we_t): two rows of the transposed matrices per request
                     std::vector<_Float16> wr2((size_t)18 * 384 * 8), we2((size_t)24 * 288 * 8);
@@ -1245,10 +1255,10 @@ static int forward_lane(mmc_backbone* bb, mmc_backbone::Lane& ws, const uint8_t*
             _Float16* t = x; x = y; y = t;
             continue;
         }
-        if (B.pp && B.fused && B.t_wr) {
+        if (B.pp && B.fused && B.t_wrg) {
             // squeeze-excite + project, one patch per workgroup (proj_patch_kernel): no gate tensor, one launch
             ProjPatchArgs pa{};
-            pa.X = ws.dwbuf; pa.pool_part = ws.pool_part; pa.wr_t = B.t_wr; pa.br = B.pp_br; pa.we_t = B.t_we; pa.be = B.se_be;
+            pa.X = ws.dwbuf; pa.pool_part = ws.pool_part; pa.wr_g = B.t_wrg; pa.br = B.pp_br; pa.we_t = B.t_we; pa.be = B.se_be;
             pa.wfrag = B.pp_w; pa.bias = B.pp_b; pa.res = B.skip ? x : nullptr; pa.Y = y;
             pa.dbg_gate = bb->keep ? ws.gate : nullptr;
             pa.dbg_clk = bb->keep ? bb->dbg_clk : nullptr;
