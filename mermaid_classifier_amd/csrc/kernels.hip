@@ -1433,13 +1433,32 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
             }
     }
     if (WLDS) {
+        // eight 16-byte pieces per thread and round trip (as a rolled `dst[i] = src[i]` loop every piece was a load, s_waitcnt vmcnt(0),
+        // ds_write: B4's 7x7 stage stages 84 KB per workgroup = 21 exposed L2 round trips before the first MFMA)
         const uint4* src = reinterpret_cast<const uint4*>(Wfrag + (size_t)chunk * NTC * KSTEPS * 512);
         uint4* dst = reinterpret_cast<uint4*>(smem + wfr_off);
-        for (int i = tid; i < NTC * KSTEPS * 64; i += 256) dst[i] = src[i];
+        constexpr int NPC = NTC * KSTEPS * 64;
+        for (int i0 = tid; i0 < NPC; i0 += 8 * 256) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[i0 + 256 * u < NPC ? i0 + 256 * u : NPC - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + 256 * u < NPC) dst[i0 + 256 * u] = v[u];
+        }
     }
-    for (int i = tid; i < KS * KS * CC; i += 256) {
-        const int tap = i / CC, c = i - tap * CC;
-        wl[i] = Wdw[(size_t)tap * Ce + chunk * CC + c];
+    {
+        constexpr int NTAP = KS * KS * CC, NIT = (NTAP + 255) / 256;
+        float tv[NIT];   // (all requests first, see above)
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + 256 * u < NTAP ? tid + 256 * u : NTAP - 1;
+            const int tap = i / CC, c = i - tap * CC;
+            tv[u] = Wdw[(size_t)tap * Ce + chunk * CC + c];
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u)
+            if (tid + 256 * u < NTAP) wl[tid + 256 * u] = tv[u];
     }
     if (tid < CC) bl[tid] = bexp[chunk * CC + tid];
     __syncthreads();
@@ -1538,11 +1557,21 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { wk[kx][j] = w0[j]; wk[kx][4 + j] = w1[j]; }
                     }
+                    // the row's NX operands in one LDS round trip (clamped addresses, zeros selected afterwards): read behind
+                    // `if (inside)` next to their taps they were NX dependent round trips per kernel row
+                    uint4 vrow[NX];
 #pragma unroll
                     for (int xr = 0; xr < NX; ++xr) {
                         const int ix = ox * ST - pad + xr;
-                        uint4 v = {0u, 0u, 0u, 0u};
-                        if (ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(smem + (rbase + ix) * ES + cg * 16);
+                        const int ixc = ix < 0 ? 0 : (ix < W ? ix : W - 1);
+                        vrow[xr] = *reinterpret_cast<const uint4*>(smem + (rbase + ixc) * ES + cg * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int xr = 0; xr < NX; ++xr) {
+                        const int ix = ox * ST - pad + xr;
+                        const bool in = ix >= 0 && ix < W;
+                        const uint4 v = {in ? vrow[xr].x : 0u, in ? vrow[xr].y : 0u, in ? vrow[xr].z : 0u, in ? vrow[xr].w : 0u};
 #pragma unroll
                         for (int t = 0; t < TW; ++t) {
                             const int kx = xr - t * ST;
