@@ -1,5 +1,5 @@
 // mmc_api.cpp -- C ABI (include/mmc.h) and the EfficientNet-B0 launch schedule.
-// Host C++ only; kernels live in kernels.hip.  No torch, no CUDA shims.
+// Host C++ only; kernels live in k_*.hip.  No torch, no CUDA shims.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -101,7 +101,7 @@ static ArchDef make_arch(int arch)
     A.feat = round_filters(1280, width);
     return A;
 }
-// Scaled activation domain (kernels.hip, silu_scaled): every SiLU output is stored times log2(e).
+// Scaled activation domain (device_common.h, silu_scaled): every SiLU output is stored times log2(e).
 // Producers (stem, expand, depthwise, head) get weights/bias times LOG2E, consumers times 1/LOG2E;
 // for the depthwise taps the two cancel, so only its bias is scaled.
 static const double LOG2E = 1.4426950408889634;

@@ -157,6 +157,8 @@ def test_product_package_never_imports_the_oracle():
         txt = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
     for f in (src / "csrc").iterdir():
+        if not f.is_file():
+            continue   # (csrc/_obj: the build's object files)
         assert "oracle" not in f.read_text(errors="ignore").lower().replace("oracle/efficientnet_b0_ref.py", ""), f
 
 
