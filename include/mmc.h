@@ -183,6 +183,27 @@ int mmc_trainer_adam_state(mmc_trainer* t, int which, int set, float* const* W, 
  * _forward_probs, torch_classifier.py:332-376, stays on the host). */
 int mmc_trainer_logits(mmc_trainer* t, const float* X, int64_t n, float* logits, void* hip_stream);
 
+/* ---- multi-GPU: the gather of the sharded path --------------------------------------------------------------------
+ * The path shards by patches (contiguous blocks of the row range per rank, weights replicated, no exchange during compute);
+ * its one exchange step is the all-gather of the ranks' (n_r, 1280) feature blocks.  Replaces: nothing in the reference's
+ * code -- it scales out as one job per source id (scripts/launch_processing.py:59-66, 199-233) and the matrices meet on S3;
+ * SURVEY.md section 8(b) sketches this entry.  The Python package does the same through torch.distributed
+ * (mermaid_classifier_amd/dist.py: FeatureGatherer); these entries give a non-Python host the same step through this
+ * header alone.  One process per GPU; librccl is resolved at the first call (dlopen: the copy the process already has,
+ * else ROCm's; MMC_RCCL_LIBRARY overrides), so single-GPU users never load it.
+ *   mmc_dist_unique_id  rank 0 makes the 128-byte id and hands it to the other ranks out of band (file, env, TCP, MPI)
+ *   mmc_dist_create     collective: every rank calls it with the same id, its rank, the world size and its device
+ *   mmc_gather_features collective, asynchronous on `hip_stream`: local = this rank's n_local x dim fp32 block (device),
+ *                       all = sum(counts) x dim (device) on EVERY rank, rank r's block at row sum(counts[0..r));
+ *                       counts = host array of `world` block heights, or NULL when every rank holds n_local rows. */
+#define MMC_DIST_ID_BYTES 128
+typedef struct mmc_dist mmc_dist;
+int mmc_dist_unique_id(unsigned char id[MMC_DIST_ID_BYTES]);
+int mmc_dist_create(const unsigned char id[MMC_DIST_ID_BYTES], int rank, int world, int device, mmc_dist** out);
+void mmc_dist_destroy(mmc_dist* d);
+int mmc_gather_features(mmc_dist* d, const float* local, int64_t n_local, int dim, const int64_t* counts, float* all,
+                        void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SYMBOLS = [
     "mmc_head_create", "mmc_head_destroy", "mmc_head_input_dim", "mmc_head_num_classes", "mmc_head_predict",
     "mmc_trainer_create", "mmc_trainer_destroy", "mmc_trainer_partial_fit", "mmc_trainer_partial_fit_ordered", "mmc_trainer_get_params", "mmc_trainer_adam_state",
     "mmc_trainer_logits",
+    "mmc_dist_unique_id", "mmc_dist_create", "mmc_dist_destroy", "mmc_gather_features",
 ]
 
 
@@ -105,6 +106,14 @@ def _load() -> C.CDLL:
     lib.mmc_trainer_adam_state.argtypes = [vp, i32, i32, C.POINTER(fp), C.POINTER(fp), C.POINTER(C.c_longlong)]
     lib.mmc_trainer_logits.restype = i32
     lib.mmc_trainer_logits.argtypes = [vp, vp, i64, vp, vp]
+    lib.mmc_dist_unique_id.restype = i32
+    lib.mmc_dist_unique_id.argtypes = [vp]
+    lib.mmc_dist_create.restype = i32
+    lib.mmc_dist_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.mmc_dist_destroy.restype = None
+    lib.mmc_dist_destroy.argtypes = [vp]
+    lib.mmc_gather_features.restype = i32
+    lib.mmc_gather_features.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     return lib
 
 

@@ -29,6 +29,7 @@ SOURCES = {
     "k_tail.hip": KERNEL_HEADERS,
     "trainer.hip": ["../../include/mmc.h"],
     "mmc_api.cpp": ["kernels.h", "../../include/mmc.h"],
+    "mmc_dist.cpp": ["../../include/mmc.h"],
 }
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",
          "-mllvm", "-amdgpu-mfma-vgpr-form",   # MFMA results land in VGPRs: no v_accvgpr_read per element

@@ -81,6 +81,63 @@ class FeatureGatherer:
         return self._finish()
 
 
+class NativeGatherer:
+    """The same exchange through the C ABI alone (include/mmc.h: mmc_dist_unique_id / mmc_dist_create /
+    mmc_gather_features -- RCCL resolved by the library, no torch.distributed): what a non-Python host binds.  Rank 0
+    makes the id with `NativeGatherer.unique_id()` and hands the 128 bytes to the other ranks out of band; every rank
+    then constructs `NativeGatherer(id, rank, world, device)` (a collective) and calls `gather(local, n_total)` with its
+    contiguous block (shard_range) as a cuda tensor; the (n_total, D) matrix comes back on every rank, asynchronously on
+    the current stream."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_ubyte * NativeGatherer.ID_BYTES)()
+        _lib.check(_lib.lib().mmc_dist_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        import ctypes as C
+        from . import _lib
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"unique id must be {self.ID_BYTES} bytes, got {len(unique_id)}")
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self._lib = _lib
+        self._h = C.c_void_p()
+        buf = (C.c_ubyte * self.ID_BYTES).from_buffer_copy(unique_id)
+        _lib.check(_lib.lib().mmc_dist_create(buf, self.rank, self.world, self.device, C.byref(self._h)))
+
+    def gather(self, local, n_total: int):
+        import ctypes as C
+        import torch
+        lo, hi = shard_range(int(n_total), self.rank, self.world)
+        if local.dim() != 2 or local.shape[0] != hi - lo or local.dtype != torch.float32 or not local.is_cuda:
+            raise ValueError(f"rank {self.rank} must hold a cuda float32 ({hi - lo}, D) block, got {tuple(local.shape)} {local.dtype}")
+        local = local.contiguous()
+        d = local.shape[1]
+        out = local.new_empty((int(n_total), d))
+        counts = (C.c_int64 * self.world)(*[b - a for a, b in (shard_range(int(n_total), r, self.world) for r in range(self.world))])
+        even = int(n_total) % self.world == 0
+        st = torch.cuda.current_stream(local.device).cuda_stream
+        self._lib.check(self._lib.lib().mmc_gather_features(self._h, local.data_ptr(), hi - lo, d, None if even else counts,
+                                                            out.data_ptr(), st))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lib().mmc_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def gather_features(local, n_total: int, group=None):
     """All-gather ragged (n_local, D) blocks into the (n_total, D) matrix, rows in global patch order.
     `local` is a torch tensor (cuda for nccl/RCCL, cpu for gloo).  Blocks are padded to the largest

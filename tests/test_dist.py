@@ -209,3 +209,85 @@ def _nccl_worker(rank, world, port, n_total, q):
         q.put((rank, out[:, 0].cpu().numpy()))
     finally:
         dist.destroy_process_group()
+
+
+# ---- the same exchange through the C ABI alone (include/mmc.h: mmc_dist_* / mmc_gather_features) ----
+
+def test_native_gatherer_rejects_a_malformed_id_without_touching_rccl():
+    from mermaid_classifier_amd.dist import NativeGatherer
+    with pytest.raises(ValueError, match="128 bytes"):
+        NativeGatherer(b"short", 0, 1)
+
+
+def test_c_abi_gather_rejects_bad_arguments():
+    from mermaid_classifier_amd import _lib
+    lib = _lib.lib()
+    assert lib.mmc_dist_unique_id(None) == _lib.MMC_ERR_ARG
+    assert lib.mmc_gather_features(None, None, 0, 1280, None, None, None) == _lib.MMC_ERR_ARG
+    assert b"bad argument" in lib.mmc_last_error()
+    lib.mmc_dist_destroy(None)   # a no-op, as free(NULL)
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_world_of_one_on_the_device():
+    """mmc_dist_unique_id -> mmc_dist_create -> mmc_gather_features with one rank: RCCL is resolved by the library itself
+    (no torch.distributed), the block comes back unchanged, counts-less and with explicit counts."""
+    from mermaid_classifier_amd import _lib
+    from mermaid_classifier_amd.dist import NativeGatherer
+    import ctypes as C
+    g = NativeGatherer(NativeGatherer.unique_id(), 0, 1, device=0)
+    try:
+        local = torch.arange(7 * 1280, dtype=torch.float32, device="cuda").view(7, 1280)
+        out = g.gather(local, 7)
+        torch.cuda.synchronize()
+        assert out.data_ptr() != local.data_ptr()
+        np.testing.assert_array_equal(out.cpu().numpy(), local.cpu().numpy())
+        out2 = torch.zeros_like(local)
+        counts = (C.c_int64 * 1)(7)
+        _lib.check(_lib.lib().mmc_gather_features(g._h, local.data_ptr(), 7, 1280, counts, out2.data_ptr(), None))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out2.cpu().numpy(), local.cpu().numpy())
+        counts[0] = 6   # a block height that contradicts n_local is refused before anything is sent
+        assert _lib.lib().mmc_gather_features(g._h, local.data_ptr(), 7, 1280, counts, out2.data_ptr(), None) == _lib.MMC_ERR_ARG
+    finally:
+        g.close()
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_two_ranks_ragged():
+    """Two processes, one GPU each, the id handed over through a file: needs two GPUs (the 1-GPU test box skips it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import tempfile
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as td:
+        procs = [ctx.Process(target=_native_worker, args=(r, 2, os.path.join(td, "id"), 11, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=300) for _ in range(2)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    for rank, col0 in results:
+        np.testing.assert_array_equal(col0, np.arange(11))
+
+
+def _native_worker(rank, world, id_path, n_total, q):
+    import time
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from mermaid_classifier_amd.dist import NativeGatherer, shard_range
+    torch.cuda.set_device(rank)
+    if rank == 0:
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(NativeGatherer.unique_id())
+        os.replace(id_path + ".tmp", id_path)
+    while not os.path.exists(id_path):
+        time.sleep(0.05)
+    g = NativeGatherer(open(id_path, "rb").read(), rank, world, device=rank)
+    lo, hi = shard_range(n_total, rank, world)
+    local = torch.arange(lo, hi, dtype=torch.float32, device="cuda").view(-1, 1).repeat(1, 4)
+    out = g.gather(local, n_total)
+    torch.cuda.synchronize()
+    q.put((rank, out[:, 0].cpu().numpy()))
+    g.close()
