@@ -524,9 +524,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const _Float16* __restrict_
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
                 h8 o;
+                silu_scaled_staged(acc[t]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float y = silu_scaled(acc[t][j]);
+                    const float y = acc[t][j];
                     pooled[j] += y;
                     o[j] = (_Float16)y;
                 }
@@ -1280,10 +1281,13 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
                     a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[ks], xf[pr][1][ks], a1, 0, 0, 0);
                 }
                 h4 o0, o1;
+                {
+                    float sv[8];   // staged over the pair's eight values (packed adds / products, no dependent chain per value): same bits
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o0[j] = (_Float16)silu_scaled(a0[j]);
-                    o1[j] = (_Float16)silu_scaled(a1[j]);
+                    for (int j = 0; j < 4; ++j) { sv[j] = a0[j]; sv[4 + j] = a1[j]; }
+                    silu_scaled_staged(sv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o0[j] = (_Float16)sv[j]; o1[j] = (_Float16)sv[4 + j]; }
                 }
                 if (p[pr][0] < P) *reinterpret_cast<h4*>(smem + p[pr][0] * ES + (t * 16 + 4 * q) * 2) = o0;
                 if (p[pr][1] < P) *reinterpret_cast<h4*>(smem + p[pr][1] * ES + (t * 16 + 4 * q) * 2) = o1;
@@ -1371,9 +1375,10 @@ __global__ __launch_bounds__(256) void mbconv_a_kernel(const _Float16* __restric
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     h8 o;
+                    silu_scaled_staged(acc[t]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float y = silu_scaled(acc[t][j]);
+                        const float y = acc[t][j];
                         pooled[pb][j] += y;
                         o[j] = (_Float16)y;
                     }
