@@ -324,3 +324,37 @@ def test_fp8_e4m3_encoder_matches_an_independent_implementation():
     _lib.check(_lib.lib().mmc_fp8_e4m3_encode(x.ctypes.data, out.ctypes.data, len(x)))
     want = torch.from_numpy(x).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
     assert np.array_equal(out, want)
+
+
+def test_build_recompiles_only_stale_translation_units(tmp_path, monkeypatch):
+    """build.py's staleness rule: an object is stale when its source or one of the headers it includes is newer; the library
+    when any source or header is.  (Pure host logic on temporary files: hipcc is not run.)"""
+    import os
+    import time
+    from mermaid_classifier_amd import build as B
+    csrc = tmp_path / "pkg" / "csrc"
+    (tmp_path / "include").mkdir()
+    csrc.mkdir(parents=True)
+    for src, deps in B.SOURCES.items():
+        for f in [src] + deps:
+            p = (csrc / f)
+            p.parent.mkdir(parents=True, exist_ok=True)
+            p.write_text("")
+    obj = csrc / "_obj"
+    obj.mkdir()
+    monkeypatch.setattr(B, "CSRC", csrc)
+    monkeypatch.setattr(B, "OBJ", obj)
+    monkeypatch.setattr(B, "OUT", tmp_path / "pkg" / "lib.so")
+    assert B.needs_build() and all(B._stale(s) for s in B.SOURCES)
+    now = time.time()
+    for s in B.SOURCES:
+        (obj / (s + ".o")).write_text("")
+        os.utime(obj / (s + ".o"), (now + 10, now + 10))
+    B.OUT.write_text("")
+    os.utime(B.OUT, (now + 20, now + 20))
+    assert not B.needs_build() and not any(B._stale(s) for s in B.SOURCES)
+    os.utime(csrc / "k_tail.hip", (now + 30, now + 30))            # one kernel file edited: only its object is stale
+    assert B.needs_build() and [s for s in B.SOURCES if B._stale(s)] == ["k_tail.hip"]
+    os.utime(csrc / "k_tail.hip", (now, now))
+    os.utime(csrc / "device_common.h", (now + 30, now + 30))       # the shared header: the four kernel units, nothing else
+    assert sorted(s for s in B.SOURCES if B._stale(s)) == ["k_early.hip", "k_generic.hip", "k_mid.hip", "k_tail.hip"]

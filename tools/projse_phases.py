@@ -28,7 +28,7 @@ def main():
         clk = bb.read_activation(f"b{blk}.clk", n * 8).reshape(n, 8)[:, :8]
         med = np.median(clk, axis=0)
         print(f"b{blk}.projse: prologue {med[0]:7.0f}  gemm {med[1]:7.0f} cycles (wave 0, last pair: k-loop {med[2]:7.0f}); "
-              f"prologue barriers at pooled {med[3]:.0f}  fc1 {med[4]:.0f}  reduce {med[5]:.0f}  fc2 {med[6]:.0f}  weights-in-LDS {med[7]:.0f}")
+              f"prologue barriers at pooled {med[3]:.0f}  fc1 (incl. its in-wave reduce) {med[4]:.0f}  fc2 {med[6]:.0f}  weights-in-LDS {med[7]:.0f}")
 
 if __name__ == "__main__":
     main()
