@@ -689,7 +689,7 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
                         }
             // B4: squeeze-excite + project per patch wherever proj_patch_kernel has the shape (blocks 6-15) and Cs fits its 32 slots
             const bool fp8_blk = bb->fp8 && B.Ho <= fp8_maxh;
-            const bool b4_pp = !fp8_blk && fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
+            const bool b4_pp = !fp8_blk && fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 28 &&
                                proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0);
             const bool pp_blk = (projse_enabled && i >= 3 && i <= 10) || (tail_enabled && i == 11) || b4_pp;
             if ((tail_enabled && i >= 12 && i <= 15 && B.cs == 48) || pp_blk) {
@@ -789,7 +789,7 @@ extern "C" int mmc_backbone_create_ex(const void* packed, size_t nbytes, int arc
                 TRY_OR_FREE(dev_upload(bb, &bb->b0_pre_w, wf));
             }
             if ((projse_enabled && i >= 3 && i <= 10) ||
-                (fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 32 &&
+                (fuse_generic && !(pp_env && pp_env[0] == '0') && B.has_expand && B.cs <= 28 &&
                  proj_patch_has(B.ce, B.d.cout, B.Ho * B.Ho, B.skip ? 1 : 0))) {
                 // proj_patch_kernel: fragment order as below, K and N zero-padded to whole fragments
                 const int ks32 = proj_patch_ksteps(B.ce), nf = (B.d.cout + 15) / 16;
