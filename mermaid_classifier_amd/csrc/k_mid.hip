@@ -609,7 +609,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     // The DMA goes out in three slices, one in front of each barrier of the chain: a wave's memory queue holds ~64 requests and takes
     // ~40 cycles per 1-KB piece, so wave 7 issuing all of them (up to 147) in front of the pooled barrier held every other wave there
     // for up to 6 k cycles (phase clock: pooled barrier at 10-11 k cycles for K = 672, 5 k for K = 144).  Slice sizes are what the
-    // other waves' work between two barriers covers; wave 7 does nothing else in the prologue (the reduce moved to wave 0).
+    // other waves' work between two barriers covers; wave 7 does nothing else in the prologue (FC1's reduction happens inside the FC1 waves).
     constexpr int NW = NF * KS;
     constexpr int DS0 = NW < 44 ? NW : 44, DS1 = NW - DS0 < 50 ? NW - DS0 : 50;
     // (Every workgroup fetches the same image in the same order at about the same time; starting each at a different sixteenth of it
