@@ -624,6 +624,12 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         PIN_VMEM();
     };
     h8 xc[2][CK], xn[2][CK];
+    f4 bv[NF];   // project bias of this lane's four output channels per fragment
+    const GLOBAL_AS float* biasg = sgpr_ptr<float>(a.bias);
+    auto load_bias = [&]() {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) bv[nf] = gload<f4>(biasg, (unsigned)(16 * nf + 4 * q) * 4u);
+    };
     // Wave 7 runs its own straight-line path with the chain's four barriers in it: hipcc cannot count vmcnt across a DMA (LDS-DMA
     // pieces retire out of order with plain loads), so in a shared path every wave would meet s_waitcnt vmcnt(0) at each use of a
     // loaded register behind a point where a DMA MAY be in flight -- FC2 would wait for the first pixel fragments, and so on.
@@ -634,6 +640,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
         dma(std::integral_constant<int, DS0>{}, std::integral_constant<int, DS0 + DS1>{});
         T7_BAR();   // FC1
         dma(std::integral_constant<int, DS0 + DS1>{}, std::integral_constant<int, NW>{});
+        load_bias();
         if (7 < NPAIR) { load_chunk(7, 0, xc); PIN_VMEM(); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA has landed
         T7_BAR();   // FC2 / gate
@@ -683,6 +690,7 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
 #pragma unroll
         for (int j = 0; j < 28; ++j) w2[j] = gload<uint32_t>(we_t, (unsigned)(((j < CSP ? j : 0) * K + (fc2_thr ? k2 : 0)) * 2));
         const float be0 = fc2_thr ? a.be[k2] : 0.f, be1 = fc2_thr ? a.be[k2 + 1] : 0.f;
+        load_bias();   // (the project's bias, behind the chain's inputs: requested at the start of the GEMM it was an exposed round trip)
         const float brv = a.br[4 * wj + (lane & 3)];   // squeeze bias of output 4 * wave + lane (lanes 0 .. 3 finish FC1; br is padded to 32)
     PIN_VMEM();
     __builtin_amdgcn_s_barrier();
@@ -764,9 +772,6 @@ __global__ __launch_bounds__(512) void proj_patch_kernel(ProjPatchArgs a)
     if (a.dbg_clk && tid == 0) a.dbg_clk[(size_t)b * 8 + 7] = (float)((long long)__builtin_readcyclecounter() - tk0);
     if (a.dbg_clk) tk1 = (long long)__builtin_readcyclecounter();
     // ---- project: Y[pixel][n] = sum_k (X[pixel][k] * gate[k]) W[n][k] + bias (+ residual) ----
-    f4 bv[NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) bv[nf] = *reinterpret_cast<const f4*>(a.bias + 16 * nf + 4 * q);
 #pragma unroll 1
     for (int pr = wave; pr < NPAIR; pr += 8) {
         f4 acc[2][NF];
