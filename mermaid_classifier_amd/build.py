@@ -2,7 +2,7 @@
 
     python -m mermaid_classifier_amd.build [--force]
 
-One object per translation unit (the kernels are four .hip files by layer group, plus the trainer and the C-ABI / schedule),
+One object per translation unit (the kernels are five .hip files by layer group, plus the trainer and the C-ABI / schedule),
 compiled in parallel and only when the source or one of its headers is newer than the object; then one link.  Objects live in
 csrc/_obj/ (git-ignored and gpurun-ignored: only the linked library travels to the GPU box).
 """
@@ -24,6 +24,7 @@ KERNEL_HEADERS = ["device_common.h", "kernels.h"]
 # translation unit -> headers it includes
 SOURCES = {
     "k_generic.hip": KERNEL_HEADERS,
+    "k_mbconv.hip": KERNEL_HEADERS,
     "k_early.hip": KERNEL_HEADERS,
     "k_mid.hip": KERNEL_HEADERS,
     "k_tail.hip": KERNEL_HEADERS,

@@ -1,5 +1,5 @@
 // device_common.h -- typedefs, inline-asm wrappers and small device helpers shared by the kernel translation units
-// (k_generic.hip, k_early.hip, k_mid.hip, k_tail.hip).  gfx950 only.
+// (k_generic.hip, k_mbconv.hip, k_early.hip, k_mid.hip, k_tail.hip).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

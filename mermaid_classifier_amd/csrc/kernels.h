@@ -1,4 +1,4 @@
-// kernels.h -- launcher interface between mmc_api.cpp (network schedule, C ABI) and the kernel translation units (k_generic.hip, k_early.hip, k_mid.hip, k_tail.hip).
+// kernels.h -- launcher interface between mmc_api.cpp (network schedule, C ABI) and the kernel translation units (k_generic.hip, k_mbconv.hip, k_early.hip, k_mid.hip, k_tail.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
