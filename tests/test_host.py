@@ -358,3 +358,17 @@ def test_build_recompiles_only_stale_translation_units(tmp_path, monkeypatch):
     os.utime(csrc / "k_tail.hip", (now, now))
     os.utime(csrc / "device_common.h", (now + 30, now + 30))       # the shared header: the five kernel units, nothing else
     assert sorted(s for s in B.SOURCES if B._stale(s)) == ["k_early.hip", "k_generic.hip", "k_mbconv.hip", "k_mid.hip", "k_tail.hip"]
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/mmc.h is what a C (or cgo / JNI / FFI) host includes: it must compile as C99, warnings as errors."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text(f'#include "{ROOT / "include" / "mmc.h"}"\n'
+                   "int main(void) { unsigned char id[MMC_DIST_ID_BYTES]; mmc_dist* d = 0; (void)id; (void)d; return mmc_version() == 0; }\n")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
