@@ -1,6 +1,8 @@
 """-m gpu: end-to-end parity of the HIP path, called through the C ABI, against the CPU oracle
 and the committed golden fixtures."""
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -531,3 +533,36 @@ def test_phase_clock_build_gives_the_same_features(checkpoint_path, monkeypatch)
         assert (clk[ran][:, 1:5, :6] > 0).all()                            # every phase of blocks 12..15
     finally:
         bc.close()
+
+
+def test_plain_c_host_gets_the_same_features(tmp_path, checkpoint_path):
+    """examples/c_host.c -- a C99 program with nothing but include/mmc.h and libmermaid_mi355.so (host buffers, no torch, no HIP calls
+    of its own) -- built with gcc and run on the packed weights: its features are bit for bit those of the Python path."""
+    import shutil
+    import subprocess
+    from mermaid_classifier_amd import weights as W
+    from mermaid_classifier_amd.backbone import Backbone
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "mermaid_classifier_amd"
+    exe = tmp_path / "c_host"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I", str(root / "include"), str(root / "examples" / "c_host.c"),
+                        "-o", str(exe), "-L", str(libdir), "-lmermaid_mi355", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with open(checkpoint_path, "rb") as f:
+        blob = W.pack_from_stream(f, W.get_arch(None))
+    (tmp_path / "w.mmcw").write_bytes(blob)
+    patches = np.random.default_rng(42).integers(0, 255, (5, 224, 224, 3), dtype=np.uint8)
+    (tmp_path / "p.u8").write_bytes(patches.tobytes())
+    r = subprocess.run([str(exe), str(tmp_path / "w.mmcw"), str(tmp_path / "p.u8"), "5", str(tmp_path / "f.f32")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "5 patches -> (5, 1280) features" in r.stdout
+    got = np.fromfile(tmp_path / "f.f32", dtype=np.float32).reshape(5, 1280)
+    bb = Backbone(str(checkpoint_path), device=0, max_batch=64)
+    try:
+        want = bb.extract(patches)
+    finally:
+        bb.close()
+    np.testing.assert_array_equal(got, np.asarray(want))
