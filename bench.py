@@ -411,6 +411,9 @@ def main():
                     "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_us": ms / launches * 1e3, "launches_per_step": launches // args.profile_passes,
                     "patches_per_launch": sub,
+                    # the lanes run this kernel side by side (kernel trace: in lockstep), each launch on its share of the CUs, while
+                    # `peak` is the whole chip's: the chip as a whole is at lanes x frac of that peak while the kernel runs
+                    "launches_in_flight": bb.lanes, "frac_all_launches_in_flight": bb.lanes * achieved / peak,
                     "alg_bytes_per_launch": nbytes / launches, "alg_flops_per_launch": nflops / launches,
                     "whole_net": {"alg_GB_per_step": tot["bytes"] / 1e9,
                                   "hbm_frac_at_value": tot["bytes_per_patch"] * value / 1e9 / schedule.HBM_PEAK_GBS,
